@@ -1,0 +1,555 @@
+"""Big-integer CPU oracle for the k256 / p256 / p384 hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is imported, linked or
+executed by the product (``rustcrypto-elliptic-curves_amd/``).  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` use it,
+and only as the checker.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks this model against
+every known-answer vector the reference holds for the path (scraped into
+``tests/golden/*.json`` by ``tests/golden/make_fixtures.py``): the group ADD/MUL
+vectors, the ECDSA d->Q and k->r vectors, the hash2curve Q0+Q1=P triples, the
+field doubling vectors and the risc0 field KATs.
+
+The reference is pure Rust and cannot be built in this image (no rustc/cargo;
+un-vendored crates), so this is a restatement.  Two layers:
+
+* an *independent* affine model (``affine_add`` / ``affine_mul``) - textbook
+  chord-and-tangent arithmetic on Python integers, used to pin the vectors, and
+* a *faithful* restatement of the reference algorithms whose intermediate
+  structure is observable: the Renes-Costello-Batina complete formulas returning
+  exact (X, Y, Z) triples, the GLV split, the signed radix-16 recoding, the
+  k256 ``lincomb`` / ``mul_by_generator`` loops and the primeorder 4-bit window
+  ``mul``.  Field arithmetic is exact, so evaluating the same formulas on
+  integers mod p gives the same canonical (X, Y, Z) bytes as the reference's
+  lazily-reduced 5x52 / Montgomery limbs after ``normalize`` / ``to_canonical``.
+
+All paths cited are relative to /root/reference.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class Curve:
+    name: str
+    p: int          # base field modulus
+    n: int          # group order
+    a: int          # equation a (mod p)
+    b: int          # equation b
+    gx: int
+    gy: int
+    nbytes: int     # canonical field / scalar width
+
+    @property
+    def G(self):
+        return (self.gx, self.gy, 1)
+
+
+# k256/src/lib.rs:76-79 (ORDER), k256/src/arithmetic/affine.rs:63-75 (GENERATOR),
+# k256/src/arithmetic.rs:26-34 (CURVE_EQUATION_B = 7)
+K256 = Curve(
+    "k256",
+    p=2**256 - 2**32 - 977,
+    n=0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
+    a=0,
+    b=7,
+    gx=0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798,
+    gy=0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8,
+    nbytes=32,
+)
+# p256/src/arithmetic/field.rs:22 (MODULUS), p256/src/lib.rs:74-108 (ORDER), p256/src/arithmetic.rs:37-59
+_P256_P = 0xFFFFFFFF00000001000000000000000000000000FFFFFFFFFFFFFFFFFFFFFFFF
+P256 = Curve(
+    "p256",
+    p=_P256_P,
+    n=0xFFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551,
+    a=_P256_P - 3,
+    b=0x5AC635D8AA3A93E7B3EBBD55769886BC651D06B0CC53B0F63BCE3C3E27D2604B,
+    gx=0x6B17D1F2E12C4247F8BCE6E563A440F277037D812DEB33A0F4A13945D898C296,
+    gy=0x4FE342E2FE1A7F9B8EE7EB4A7C0F9E162BCE33576B315ECECBB6406837BF51F5,
+    nbytes=32,
+)
+# p384/src/arithmetic/field.rs:43-45 (MODULUS), p384/src/lib.rs:50-64 (ORDER), p384/src/arithmetic.rs:36-61
+_P384_P = 2**384 - 2**128 - 2**96 + 2**32 - 1
+P384 = Curve(
+    "p384",
+    p=_P384_P,
+    n=0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFC7634D81F4372DDF581A0DB248B0A77AECEC196ACCC52973,
+    a=_P384_P - 3,
+    b=0xB3312FA7E23EE7E4988E056BE3F82D19181D9C6EFE8141120314088F5013875AC656398D8A2ED19D2A85C8EDD3EC2AEF,
+    gx=0xAA87CA22BE8B05378EB1C71EF320AD746E1D3B628BA79B9859F741E082542A385502F25DBF55296C3A545E3872760AB7,
+    gy=0x3617DE4A96262C6F5D9E98BF9292DC29F8F41DBD289A147CE9DA3113B5F0B8C00A60B1CE1D7E819D7A431D7C90EA0E5F,
+    nbytes=48,
+)
+CURVES = {"k256": K256, "p256": P256, "p384": P384}
+CURVE_IDS = {"k256": 0, "p256": 1, "p384": 2}
+
+IDENTITY = (0, 1, 0)   # k256 projective.rs:46-50, primeorder projective.rs:48-52
+
+
+# --------------------------------------------------------------------------------------
+# Independent affine model (None = point at infinity)
+# --------------------------------------------------------------------------------------
+def affine_add(c: Curve, P, Q):
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    x1, y1 = P
+    x2, y2 = Q
+    p = c.p
+    if x1 == x2:
+        if (y1 + y2) % p == 0:
+            return None
+        lam = (3 * x1 * x1 + c.a) * pow(2 * y1, -1, p) % p
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+    x3 = (lam * lam - x1 - x2) % p
+    return (x3, (lam * (x1 - x3) - y1) % p)
+
+
+def affine_neg(c: Curve, P):
+    return None if P is None else (P[0], (-P[1]) % c.p)
+
+
+def affine_mul(c: Curve, k: int, P):
+    k %= c.n
+    R = None
+    while k:
+        if k & 1:
+            R = affine_add(c, R, P)
+        P = affine_add(c, P, P)
+        k >>= 1
+    return R
+
+
+def on_curve(c: Curve, P) -> bool:
+    if P is None:
+        return True
+    x, y = P
+    return (y * y - (x * x * x + c.a * x + c.b)) % c.p == 0
+
+
+# --------------------------------------------------------------------------------------
+# Projective <-> affine   (k256 projective.rs:73-84; primeorder projective.rs:62-74)
+# --------------------------------------------------------------------------------------
+def to_affine(c: Curve, P):
+    """Returns (x, y, infinity) exactly as AffinePoint: identity is (0, 0, 1)."""
+    X, Y, Z = P
+    if Z % c.p == 0:
+        return (0, 0, 1)
+    zi = pow(Z, -1, c.p)
+    return (X * zi % c.p, Y * zi % c.p, 0)
+
+
+def from_affine(A):
+    """k256 projective.rs:314-323 / primeorder: affine (x,y,inf) -> projective."""
+    x, y, inf = A
+    return IDENTITY if inf else (x, y, 1)
+
+
+def to_affine_opt(c: Curve, P):
+    x, y, inf = to_affine(c, P)
+    return None if inf else (x, y)
+
+
+# --------------------------------------------------------------------------------------
+# Renes-Costello-Batina complete formulas, k256 (a = 0, b = 7)
+# --------------------------------------------------------------------------------------
+def k256_add(P, Q):
+    """k256/src/arithmetic/projective.rs:96-161 (RCB 2015 Algorithm 7)."""
+    p = K256.p
+    x1, y1, z1 = P
+    x2, y2, z2 = Q
+    xx = x1 * x2 % p
+    yy = y1 * y2 % p
+    zz = z1 * z2 % p
+    xy_pairs = ((x1 + y1) * (x2 + y2) - (xx + yy)) % p
+    yz_pairs = ((y1 + z1) * (y2 + z2) - (yy + zz)) % p
+    xz_pairs = ((x1 + z1) * (x2 + z2) - (xx + zz)) % p
+    bzz3 = 21 * zz % p
+    yy_m_bzz3 = (yy - bzz3) % p
+    yy_p_bzz3 = (yy + bzz3) % p
+    byz3 = 21 * yz_pairs % p
+    xx3 = 3 * xx % p
+    bxx9 = 21 * xx3 % p
+    return (
+        (xy_pairs * yy_m_bzz3 - byz3 * xz_pairs) % p,
+        (yy_p_bzz3 * yy_m_bzz3 + bxx9 * xz_pairs) % p,
+        (yz_pairs * yy_p_bzz3 + xx3 * xy_pairs) % p,
+    )
+
+
+def k256_add_mixed(P, A):
+    """k256/src/arithmetic/projective.rs:164-221 (RCB Algorithm 8); A = (x, y, infinity)."""
+    p = K256.p
+    x1, y1, z1 = P
+    x2, y2, inf = A
+    xx = x1 * x2 % p
+    yy = y1 * y2 % p
+    xy_pairs = ((x1 + y1) * (x2 + y2) - (xx + yy)) % p
+    yz_pairs = (y2 * z1 + y1) % p
+    xz_pairs = (x2 * z1 + x1) % p
+    bzz3 = 21 * z1 % p
+    yy_m_bzz3 = (yy - bzz3) % p
+    yy_p_bzz3 = (yy + bzz3) % p
+    byz3 = 21 * yz_pairs % p
+    xx3 = 3 * xx % p
+    bxx9 = 21 * xx3 % p
+    ret = (
+        (xy_pairs * yy_m_bzz3 - byz3 * xz_pairs) % p,
+        (yy_p_bzz3 * yy_m_bzz3 + bxx9 * xz_pairs) % p,
+        (yz_pairs * yy_p_bzz3 + xx3 * xy_pairs) % p,
+    )
+    return (x1 % p, y1 % p, z1 % p) if inf else ret   # :219 conditional_assign(self, other.is_identity())
+
+
+def k256_double(P):
+    """k256/src/arithmetic/projective.rs:225-274 (RCB Algorithm 9)."""
+    p = K256.p
+    x, y, z = P
+    yy = y * y % p
+    zz = z * z % p
+    xy2 = 2 * x * y % p
+    bzz3 = 21 * zz % p
+    bzz9 = 3 * bzz3 % p
+    yy_m_bzz9 = (yy - bzz9) % p
+    yy_p_bzz3 = (yy + bzz3) % p
+    yy_zz = yy * zz % p
+    t = 24 * 7 * yy_zz % p
+    return (
+        xy2 * yy_m_bzz9 % p,
+        (yy_m_bzz9 * yy_p_bzz3 + t) % p,
+        8 * (yy * y % p) * z % p,
+    )
+
+
+def k256_neg(P):
+    """k256 projective.rs:87-93."""
+    return (P[0], (-P[1]) % K256.p, P[2])
+
+
+# ENDOMORPHISM_BETA: k256/src/arithmetic/projective.rs:29-34
+K256_BETA = 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
+
+
+def k256_endomorphism(P):
+    """k256 projective.rs:287-293: (x*beta, y, z) = lambda * P."""
+    return (P[0] * K256_BETA % K256.p, P[1], P[2])
+
+
+# --------------------------------------------------------------------------------------
+# RCB complete formulas, a = -3 (p256 / p384)  primeorder/src/point_arithmetic.rs:199-317
+# --------------------------------------------------------------------------------------
+def am3_add(c: Curve, P, Q):
+    """primeorder/src/point_arithmetic.rs:209-238 (RCB Algorithm 4)."""
+    p, b = c.p, c.b
+    x1, y1, z1 = P
+    x2, y2, z2 = Q
+    xx = x1 * x2 % p
+    yy = y1 * y2 % p
+    zz = z1 * z2 % p
+    xy_pairs = ((x1 + y1) * (x2 + y2) - (xx + yy)) % p
+    yz_pairs = ((y1 + z1) * (y2 + z2) - (yy + zz)) % p
+    xz_pairs = ((x1 + z1) * (x2 + z2) - (xx + zz)) % p
+    bzz_part = (xz_pairs - b * zz) % p
+    bzz3_part = 3 * bzz_part % p
+    yy_m_bzz3 = (yy - bzz3_part) % p
+    yy_p_bzz3 = (yy + bzz3_part) % p
+    zz3 = 3 * zz % p
+    bxz_part = (b * xz_pairs - (zz3 + xx)) % p
+    bxz3_part = 3 * bxz_part % p
+    xx3_m_zz3 = (3 * xx - zz3) % p
+    return (
+        (yy_p_bzz3 * xy_pairs - yz_pairs * bxz3_part) % p,
+        (yy_p_bzz3 * yy_m_bzz3 + xx3_m_zz3 * bxz3_part) % p,
+        (yy_m_bzz3 * yz_pairs + xy_pairs * xx3_m_zz3) % p,
+    )
+
+
+def am3_add_mixed(c: Curve, P, A):
+    """primeorder/src/point_arithmetic.rs:247-277 (RCB Algorithm 5); A = (x, y, infinity)."""
+    p, b = c.p, c.b
+    x1, y1, z1 = P
+    x2, y2, inf = A
+    xx = x1 * x2 % p
+    yy = y1 * y2 % p
+    xy_pairs = ((x1 + y1) * (x2 + y2) - (xx + yy)) % p
+    yz_pairs = (y2 * z1 + y1) % p
+    xz_pairs = (x2 * z1 + x1) % p
+    bz_part = (xz_pairs - b * z1) % p
+    bz3_part = 3 * bz_part % p
+    yy_m_bzz3 = (yy - bz3_part) % p
+    yy_p_bzz3 = (yy + bz3_part) % p
+    z3 = 3 * z1 % p
+    bxz_part = (b * xz_pairs - (z3 + xx)) % p
+    bxz3_part = 3 * bxz_part % p
+    xx3_m_zz3 = (3 * xx - z3) % p
+    ret = (
+        (yy_p_bzz3 * xy_pairs - yz_pairs * bxz3_part) % p,
+        (yy_p_bzz3 * yy_m_bzz3 + xx3_m_zz3 * bxz3_part) % p,
+        (yy_m_bzz3 * yz_pairs + xy_pairs * xx3_m_zz3) % p,
+    )
+    return (x1 % p, y1 % p, z1 % p) if inf else ret
+
+
+def am3_double(c: Curve, P):
+    """primeorder/src/point_arithmetic.rs:286-317 (RCB Algorithm 6)."""
+    p, b = c.p, c.b
+    x, y, z = P
+    xx = x * x % p
+    yy = y * y % p
+    zz = z * z % p
+    xy2 = 2 * x * y % p
+    xz2 = 2 * x * z % p
+    bzz_part = (b * zz - xz2) % p
+    bzz3_part = 3 * bzz_part % p
+    yy_m_bzz3 = (yy - bzz3_part) % p
+    yy_p_bzz3 = (yy + bzz3_part) % p
+    y_frag = yy_p_bzz3 * yy_m_bzz3 % p
+    x_frag = yy_m_bzz3 * xy2 % p
+    zz3 = 3 * zz % p
+    bxz2_part = (b * xz2 - (zz3 + xx)) % p
+    bxz6_part = 3 * bxz2_part % p
+    xx3_m_zz3 = (3 * xx - zz3) % p
+    yy_ = (y_frag + xx3_m_zz3 * bxz6_part) % p
+    yz2 = 2 * y * z % p
+    xx_ = (x_frag - bxz6_part * yz2) % p
+    zz_ = 4 * yz2 * yy % p
+    return (xx_, yy_, zz_)
+
+
+# --------------------------------------------------------------------------------------
+# curve-dispatching wrappers (the ProjectivePoint::{add, add_mixed, double, neg} surface)
+# --------------------------------------------------------------------------------------
+def point_add(c: Curve, P, Q):
+    return k256_add(P, Q) if c.name == "k256" else am3_add(c, P, Q)
+
+
+def point_add_mixed(c: Curve, P, A):
+    return k256_add_mixed(P, A) if c.name == "k256" else am3_add_mixed(c, P, A)
+
+
+def point_double(c: Curve, P):
+    return k256_double(P) if c.name == "k256" else am3_double(c, P)
+
+
+def point_neg(c: Curve, P):
+    return (P[0], (-P[1]) % c.p, P[2])
+
+
+# --------------------------------------------------------------------------------------
+# k256 scalar-side pieces
+# --------------------------------------------------------------------------------------
+# k256/src/arithmetic/mul.rs:129-152
+K256_MINUS_LAMBDA = 0xAC9C52B33FA3CF1F5AD9E3FD77ED9BA4A880B9FC8EC739C2E0CFC810B51283CF
+K256_MINUS_B1 = 0x00000000000000000000000000000000E4437ED6010E88286F547FA90ABFE4C3
+K256_MINUS_B2 = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFE8A280AC50774346DD765CDA83DB1562C
+K256_G1 = 0x3086D221A7D46BCDE86C90E49284EB153DAA8A1471E8CA7FE893209A45DBB031
+K256_G2 = 0xE4437ED6010E88286F547FA90ABFE4C4221208AC9DF506C61571B4AE8AC47F71
+K256_LAMBDA = (K256.n - K256_MINUS_LAMBDA) % K256.n
+
+
+def k256_mul_shift_384(a: int, b: int) -> int:
+    """k256/src/arithmetic/scalar/wide64.rs:64-119 with shift = 384: round(a*b / 2^384)."""
+    prod = a * b
+    res = prod >> 384
+    if (prod >> 383) & 1:
+        res = (res + 1) % K256.n
+    return res
+
+
+def k256_decompose_scalar(k: int):
+    """k256/src/arithmetic/mul.rs:260-268: (r1, r2) with r1 + r2*lambda == k (mod n)."""
+    n = K256.n
+    c1 = k256_mul_shift_384(k, K256_G1) * K256_MINUS_B1 % n
+    c2 = k256_mul_shift_384(k, K256_G2) * K256_MINUS_B2 % n
+    r2 = (c1 + c2) % n
+    r1 = (k + r2 * K256_MINUS_LAMBDA) % n
+    return r1, r2
+
+
+def k256_is_high(s: int) -> bool:
+    """k256/src/arithmetic/scalar.rs:519-523: s > n/2 (FRAC_MODULUS_2 = (n-1)/2)."""
+    return s > (K256.n >> 1)
+
+
+def radix16_decomposition(x: int, D: int):
+    """k256/src/arithmetic/mul.rs:274-305: D signed digits in [-8, 7] (top one >= 0)."""
+    assert x >> (4 * (D - 1)) == 0
+    out = [(x >> (4 * i)) & 0xF for i in range(D - 1)] + [0]
+    for i in range(D - 1):
+        carry = (out[i] + 8) >> 4
+        out[i] -= carry << 4
+        out[i + 1] += carry
+    return out
+
+
+def k256_lookup_table(P):
+    """mul.rs:65-73: [P, 2P, ..., 8P] by repeated complete addition."""
+    pts = [P]
+    for _ in range(7):
+        pts.append(k256_add(P, pts[-1]))
+    return pts
+
+
+def k256_table_select(table, d: int):
+    """mul.rs:92-127."""
+    t = IDENTITY if d == 0 else table[abs(d) - 1]
+    return k256_neg(t) if d < 0 else t
+
+
+def k256_lincomb_ref(terms):
+    """k256/src/arithmetic/mul.rs:342-393.  terms = [(P_xyz, k)], returns exact (X, Y, Z)."""
+    tables, digits = [], []
+    for P, k in terms:
+        r1, r2 = k256_decompose_scalar(k % K256.n)
+        Pb = k256_endomorphism(P)
+        s1, s2 = k256_is_high(r1), k256_is_high(r2)
+        r1c = (K256.n - r1) % K256.n if s1 else r1
+        r2c = (K256.n - r2) % K256.n if s2 else r2
+        tables.append((k256_lookup_table(k256_neg(P) if s1 else P),
+                       k256_lookup_table(k256_neg(Pb) if s2 else Pb)))
+        digits.append((radix16_decomposition(r1c, 33), radix16_decomposition(r2c, 33)))
+    acc = IDENTITY
+    for (t1, t2), (d1, d2) in zip(tables, digits):
+        acc = k256_add(acc, k256_table_select(t1, d1[32]))
+        acc = k256_add(acc, k256_table_select(t2, d2[32]))
+    for i in range(31, -1, -1):
+        for _ in range(4):
+            acc = k256_double(acc)
+        for (t1, t2), (d1, d2) in zip(tables, digits):
+            acc = k256_add(acc, k256_table_select(t1, d1[i]))
+            acc = k256_add(acc, k256_table_select(t2, d2[i]))
+    return acc
+
+
+def k256_mul_ref(P, k: int):
+    """mul.rs:442-445: P * k = lincomb_ext(&[(P, k)])."""
+    return k256_lincomb_ref([(P, k)])
+
+
+_K256_GEN_TABLE = None
+
+
+def k256_gen_lookup_table():
+    """mul.rs:399-413: 33 tables of [1..8] * 2^(8i) * G."""
+    global _K256_GEN_TABLE
+    if _K256_GEN_TABLE is None:
+        g = K256.G
+        res = []
+        for _ in range(33):
+            res.append(k256_lookup_table(g))
+            for _ in range(8):
+                g = k256_double(g)
+        _K256_GEN_TABLE = res
+    return _K256_GEN_TABLE
+
+
+def k256_mul_by_generator_ref(k: int):
+    """mul.rs:424-439 (feature precomputed-tables)."""
+    digits = radix16_decomposition(k % K256.n, 65)
+    table = k256_gen_lookup_table()
+    acc = k256_table_select(table[32], digits[64])
+    acc2 = IDENTITY
+    for i in range(31, -1, -1):
+        acc2 = k256_add(acc2, k256_table_select(table[i], digits[2 * i + 1]))
+        acc = k256_add(acc, k256_table_select(table[i], digits[2 * i]))
+    for _ in range(4):
+        acc2 = k256_double(acc2)
+    return k256_add(acc, acc2)
+
+
+# --------------------------------------------------------------------------------------
+# primeorder scalar multiplication (p256 / p384)
+# --------------------------------------------------------------------------------------
+def primeorder_mul_ref(c: Curve, P, k: int):
+    """primeorder/src/projective.rs:106-150: unsigned 4-bit window, MSB first."""
+    k %= c.n
+    pc = [IDENTITY, P]
+    for i in range(2, 16):
+        pc.append(am3_double(c, pc[i // 2]) if i % 2 == 0 else am3_add(c, pc[i - 1], P))
+    q = IDENTITY
+    pos = c.nbytes * 8 - 4
+    while True:
+        slot = (k >> pos) & 0xF
+        q = am3_add(c, q, pc[slot])
+        if pos == 0:
+            break
+        for _ in range(4):
+            q = am3_double(c, q)
+        pos -= 4
+    return q
+
+
+def mul_ref(c: Curve, P, k: int):
+    """`&P * &k` exactly as the reference computes it (exact X, Y, Z)."""
+    return k256_mul_ref(P, k) if c.name == "k256" else primeorder_mul_ref(c, P, k)
+
+
+def mul_by_generator_ref(c: Curve, k: int):
+    """MulByGenerator: k256 mul.rs:415-440; primeorder projective.rs:422-431 (= G * k)."""
+    return k256_mul_by_generator_ref(k) if c.name == "k256" else primeorder_mul_ref(c, c.G, k)
+
+
+def lincomb_ref(c: Curve, terms):
+    """LinearCombination: k256 shares doublings (mul.rs:342-393); primeorder default is
+    x*k + y*l (primeorder/src/projective.rs:415-420) generalised to a left fold."""
+    if c.name == "k256":
+        return k256_lincomb_ref(terms)
+    acc = None
+    for P, k in terms:
+        t = primeorder_mul_ref(c, P, k)
+        acc = t if acc is None else am3_add(c, acc, t)
+    return IDENTITY if acc is None else acc
+
+
+# --------------------------------------------------------------------------------------
+# field helpers (canonical results)
+# --------------------------------------------------------------------------------------
+def field_invert(c: Curve, a: int):
+    """k256 field.rs:187-216 / p256 field.rs:357-382 / p384 field.rs:67-91: unique inverse, None for 0."""
+    a %= c.p
+    return None if a == 0 else pow(a, -1, c.p)
+
+
+def field_sqrt(c: Curve, a: int):
+    """k256 field.rs:220-255, p256 field.rs:385-411, p384 field.rs:95-117: a^((p+1)/4), checked."""
+    a %= c.p
+    r = pow(a, (c.p + 1) // 4, c.p)
+    return r if r * r % c.p == a else None
+
+
+def decompress(c: Curve, x: int, y_is_odd: int):
+    """k256 affine.rs:184-202 / primeorder affine.rs:129-150."""
+    if x >= c.p:
+        return None
+    alpha = (x * x * x + c.a * x + c.b) % c.p
+    beta = field_sqrt(c, alpha)
+    if beta is None:
+        return None
+    y = beta if (beta & 1) == (y_is_odd & 1) else (c.p - beta) % c.p
+    return (x, y)
+
+
+# --------------------------------------------------------------------------------------
+# byte helpers (canonical big-endian wire format)
+# --------------------------------------------------------------------------------------
+def i2b(c: Curve, v: int) -> bytes:
+    return int(v).to_bytes(c.nbytes, "big")
+
+
+def b2i(b: bytes) -> int:
+    return int.from_bytes(b, "big")
+
+
+def proj_bytes(c: Curve, P) -> bytes:
+    return b"".join(i2b(c, v % c.p) for v in P)
+
+
+def affine_bytes(c: Curve, A) -> bytes:
+    """x || y || infinity-byte (x = y = 0 when infinity, as AffinePoint::IDENTITY)."""
+    x, y, inf = A
+    return i2b(c, x) + i2b(c, y) + bytes([inf])
