@@ -1,0 +1,165 @@
+/* ecgpu - batched elliptic-curve arithmetic on MI355X (gfx950): C ABI.
+ *
+ * Drop-in boundary for the data-parallel hot path of risc0/RustCrypto-elliptic-curves
+ * (field mul/sqr/add/sub -> complete point add/double -> fixed/variable-base scalar
+ * multiplication -> linear combination / MSM over k256, p256, p384).  The reference exposes
+ * that path only as Rust traits (no FFI exists); each entry point below names the trait item(s)
+ * it stands in for.  INTEGRATION.md shows the `extern "C"` block and the trait impls a
+ * maintainer would add on the Rust side.
+ *
+ * Conventions
+ *  - Plain C, no callbacks, caller-owned buffers, batch first.  No Rust struct memory crosses
+ *    the boundary (the reference's types are not repr(C)): everything is canonical big-endian
+ *    bytes exactly as `to_bytes` / `to_repr` produce them.
+ *      field element / scalar : NB bytes (32 for k256/p256, 48 for p384), value < modulus
+ *      affine point           : x || y (2*NB); the identity is x = y = 0, mirroring
+ *                               AffinePoint::IDENTITY (k256 affine.rs:51-55, primeorder
+ *                               affine.rs:48-52).  Entry points that produce affine points also
+ *                               fill an optional `inf` byte array (0/1 per element) = the
+ *                               `infinity` field of AffinePoint.
+ *      projective point       : X || Y || Z (3*NB), homogeneous (x = X/Z), identity (0, 1, 0)
+ *                               (k256 projective.rs:38-50, primeorder projective.rs:37-52).
+ *  - `mem` says where the caller's buffers live: ECGPU_MEM_HOST (the library stages them
+ *    through HBM) or ECGPU_MEM_DEVICE (pointers into this GPU's HBM, 4-byte aligned; the
+ *    call is asynchronous on the context's stream).
+ *  - Every function returns 0 on success or a negative ecgpu_status; ecgpu_last_error() gives
+ *    the text.  Arithmetic on valid inputs cannot fail.  Decoding failures (scalar >= n,
+ *    coordinate >= p, point not on the curve) are reported per element by the *_validate
+ *    calls, mirroring CtOption::is_none of from_repr / from_bytes / from_encoded_point.
+ *  - Re-entrant; one context per device; calls on different contexts may run concurrently.
+ *  - There is no CPU fallback: without a usable GPU every call fails with ECGPU_ERR_NO_DEVICE.
+ */
+#ifndef ECGPU_H
+#define ECGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ecgpu_ctx ecgpu_ctx;
+
+typedef enum ecgpu_curve {
+  ECGPU_K256 = 0, /* secp256k1  k256/src/lib.rs:76-104 */
+  ECGPU_P256 = 1, /* NIST P-256 p256/src/lib.rs:74-108 */
+  ECGPU_P384 = 2  /* NIST P-384 p384/src/lib.rs:50-64 */
+} ecgpu_curve;
+
+typedef enum ecgpu_mem { ECGPU_MEM_HOST = 0, ECGPU_MEM_DEVICE = 1 } ecgpu_mem;
+
+typedef enum ecgpu_status {
+  ECGPU_OK = 0,
+  ECGPU_ERR_ARG = -1,       /* bad curve / op / format / NULL pointer */
+  ECGPU_ERR_NO_DEVICE = -2, /* no GPU, or the device is not gfx950 */
+  ECGPU_ERR_RUNTIME = -3,   /* HIP runtime error (text in ecgpu_last_error) */
+  ECGPU_ERR_UNSUPPORTED = -4
+} ecgpu_status;
+
+typedef enum ecgpu_point_format {
+  ECGPU_PT_AFFINE = 0,     /* x || y, identity = all zero */
+  ECGPU_PT_PROJECTIVE = 1  /* X || Y || Z */
+} ecgpu_point_format;
+
+/* FieldElement operations (k256/src/arithmetic/field.rs:56, p256/src/arithmetic/field.rs:43,
+ * p384/src/arithmetic/field.rs:47-63).  Results are canonical (`normalize().to_bytes()`). */
+typedef enum ecgpu_field_op {
+  ECGPU_FE_MUL = 0, /* Mul        field.rs:164-169 / p256 field.rs:293-319 / fiat_p384_mul   */
+  ECGPU_FE_SQR = 1, /* square     field.rs:172-174                                           */
+  ECGPU_FE_ADD = 2, /* Add        field_5x52.rs:264-272 / p256 field.rs:118-134              */
+  ECGPU_FE_SUB = 3, /* Sub        field.rs:425-451 / p256 field.rs:142-147                   */
+  ECGPU_FE_NEG = 4, /* Neg / negate field_5x52.rs:252-260                                    */
+  ECGPU_FE_INV = 5, /* invert     field.rs:187-216 / p256 field.rs:357-382 (0 -> 0, see doc) */
+  ECGPU_FE_SQRT = 6 /* sqrt       field.rs:220-255; non-residue -> all 0xFF                  */
+} ecgpu_field_op;
+
+/* flags for the scalar-multiplication entry points */
+enum {
+  /* Follow the reference's algorithm step for step (GLV + signed radix-16 tables for k256,
+   * 4-bit window for p256/p384) so that a PROJECTIVE result is the very (X, Y, Z) triple the
+   * reference returns.  Without it the library is free to pick the fastest schedule and only
+   * the group element (hence the affine result) is specified. */
+  ECGPU_EXACT_REFERENCE = 1u
+};
+
+/* ---- context ------------------------------------------------------------------------------ */
+int ecgpu_create(ecgpu_ctx** ctx, int device_index);
+void ecgpu_destroy(ecgpu_ctx* ctx);
+/* Use the caller's HIP stream (hipStream_t) for all launches; NULL = the context's own stream. */
+int ecgpu_set_stream(ecgpu_ctx* ctx, void* hip_stream);
+int ecgpu_synchronize(ecgpu_ctx* ctx);
+const char* ecgpu_last_error(const ecgpu_ctx* ctx);
+const char* ecgpu_version(void);
+/* NB for a curve (32 / 32 / 48), 0 for an unknown curve. */
+size_t ecgpu_field_bytes(int curve);
+/* HIP-event timer on the context's stream: bracket launches, read milliseconds. */
+int ecgpu_timer_start(ecgpu_ctx* ctx);
+int ecgpu_timer_stop(ecgpu_ctx* ctx, float* milliseconds);
+
+/* ---- base field ---------------------------------------------------------------------------- */
+/* out[i] = a[i] (op) b[i]; b is ignored (may be NULL) for unary ops. */
+int ecgpu_field_op_batch(ecgpu_ctx* ctx, int curve, int op, const uint8_t* a, const uint8_t* b,
+                         uint8_t* out, size_t n, int mem);
+
+/* ---- group law: ProjectivePoint::{add, add_mixed, double}  -------------------------------------
+ * k256 projective.rs:96-161, :164-221, :225-274; primeorder point_arithmetic.rs:209-238, :247-277,
+ * :286-317.  Complete formulas: total on every input, results are the exact (X, Y, Z) of the
+ * reference (canonical bytes). */
+int ecgpu_point_add_batch(ecgpu_ctx* ctx, int curve, const uint8_t* p_xyz, const uint8_t* q_xyz,
+                          uint8_t* out_xyz, size_t n, int mem);
+int ecgpu_point_add_mixed_batch(ecgpu_ctx* ctx, int curve, const uint8_t* p_xyz, const uint8_t* q_xy,
+                                uint8_t* out_xyz, size_t n, int mem);
+int ecgpu_point_double_batch(ecgpu_ctx* ctx, int curve, const uint8_t* p_xyz, uint8_t* out_xyz,
+                             size_t n, int mem);
+
+/* BatchNormalize::batch_normalize / to_affine (k256 projective.rs:73-84, :325-379; primeorder
+ * projective.rs:62-74, :346-413): out_xy[i] = affine(p[i]); out_inf may be NULL. */
+int ecgpu_batch_normalize(ecgpu_ctx* ctx, int curve, const uint8_t* p_xyz, uint8_t* out_xy,
+                          uint8_t* out_inf, size_t n, int mem);
+
+/* ---- scalar multiplication ------------------------------------------------------------------
+ * out[i] = scalars[i] * points[i]          `&P * &k`   k256 mul.rs:442-481, primeorder projective.rs:106-150
+ * points == NULL: out[i] = scalars[i] * G   MulByGenerator::mul_by_generator  k256 mul.rs:415-440,
+ *                                           primeorder projective.rs:422-431
+ * point_format / out_format: ecgpu_point_format.  out_inf (optional) only for affine output. */
+int ecgpu_mul_batch(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points,
+                    int point_format, uint8_t* out, int out_format, uint8_t* out_inf, size_t n,
+                    int mem, unsigned flags);
+
+/* n independent linear combinations of `terms` terms each:
+ *   out[i] = sum_j scalars[i*terms + j] * points[i*terms + j]
+ * LinearCombination::lincomb (terms = 2) / LinearCombinationExt::lincomb_ext (k256 mul.rs:313-393;
+ * primeorder default projective.rs:415-420). */
+int ecgpu_lincomb_batch(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points,
+                        int point_format, size_t terms, uint8_t* out, int out_format, uint8_t* out_inf,
+                        size_t n, int mem, unsigned flags);
+
+/* One multi-scalar multiplication out = sum_i scalars[i] * points[i] over n terms (Pippenger
+ * bucket method; the large-N form of lincomb_ext over a slice, k256 mul.rs:325-340).
+ * `out` is one point in out_format. */
+int ecgpu_msm(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points, int point_format,
+              size_t n, uint8_t* out, int out_format, int mem);
+
+/* ---- decoding checks (CtOption::is_none mirrors) ---------------------------------------------
+ * ok[i] = 1 iff scalars[i] < n   (Scalar::from_repr, k256 scalar.rs:365-368) */
+int ecgpu_validate_scalars(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, uint8_t* ok, size_t n, int mem);
+/* ok[i] = 1 iff the affine point decodes: both coordinates < p and on the curve, or the identity
+ * (AffinePoint::from_encoded_point, k256 affine.rs:241-270, primeorder affine.rs:161-195) */
+int ecgpu_validate_points(ecgpu_ctx* ctx, int curve, const uint8_t* points_xy, uint8_t* ok, size_t n, int mem);
+/* DecompressPoint::decompress (k256 affine.rs:184-202, primeorder affine.rs:129-150):
+ * out_xy[i] = (x, y) with y parity y_is_odd[i]; ok[i] = 0 (and zeros) when x >= p or no root. */
+int ecgpu_decompress_batch(ecgpu_ctx* ctx, int curve, const uint8_t* x, const uint8_t* y_is_odd,
+                           uint8_t* out_xy, uint8_t* ok, size_t n, int mem);
+
+/* ---- synthetic inputs for benchmarks (device memory only) ------------------------------------
+ * Fill device buffers with the counter-based streams specified in oracle/synth.py:
+ * scalars[i] = reduce(stream 0), points[i] = try-and-increment decompress of streams 1.. .
+ * `first_index` lets ranks generate disjoint slices of one global batch. */
+int ecgpu_synth_scalars(ecgpu_ctx* ctx, int curve, uint64_t seed, uint64_t first_index, uint8_t* d_scalars, size_t n);
+int ecgpu_synth_points(ecgpu_ctx* ctx, int curve, uint64_t seed, uint64_t first_index, uint8_t* d_points_xy, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECGPU_H */

@@ -114,15 +114,55 @@ def affine_neg(c: Curve, P):
     return None if P is None else (P[0], (-P[1]) % c.p)
 
 
+def _jac_double(c: Curve, P):
+    X, Y, Z = P
+    p = c.p
+    if Y == 0 or Z == 0:
+        return (1, 1, 0)
+    S = 4 * X * Y * Y % p
+    Mm = (3 * X * X + c.a * pow(Z, 4, p)) % p
+    X3 = (Mm * Mm - 2 * S) % p
+    Y3 = (Mm * (S - X3) - 8 * pow(Y, 4, p)) % p
+    return (X3, Y3, 2 * Y * Z % p)
+
+
+def _jac_add_affine(c: Curve, P, Q):
+    """Jacobian P + affine Q (textbook formulas with explicit special cases)."""
+    X1, Y1, Z1 = P
+    x2, y2 = Q
+    p = c.p
+    if Z1 == 0:
+        return (x2, y2, 1)
+    Z1Z1 = Z1 * Z1 % p
+    U2 = x2 * Z1Z1 % p
+    S2 = y2 * Z1 * Z1Z1 % p
+    H = (U2 - X1) % p
+    R = (S2 - Y1) % p
+    if H == 0:
+        return _jac_double(c, P) if R == 0 else (1, 1, 0)
+    HH = H * H % p
+    HHH = H * HH % p
+    V = X1 * HH % p
+    X3 = (R * R - HHH - 2 * V) % p
+    Y3 = (R * (V - X3) - Y1 * HHH) % p
+    return (X3, Y3, Z1 * H % p)
+
+
 def affine_mul(c: Curve, k: int, P):
+    """k*P by plain MSB-first double-and-add in Jacobian coordinates (one inversion at the end).
+    Independent of the RCB formulas and of every windowing trick above/below."""
     k %= c.n
-    R = None
-    while k:
-        if k & 1:
-            R = affine_add(c, R, P)
-        P = affine_add(c, P, P)
-        k >>= 1
-    return R
+    if P is None or k == 0:
+        return None
+    R = (1, 1, 0)
+    for bit in bin(k)[2:]:
+        R = _jac_double(c, R)
+        if bit == "1":
+            R = _jac_add_affine(c, R, P)
+    if R[2] == 0:
+        return None
+    zi = pow(R[2], -1, c.p)
+    return (R[0] * zi * zi % c.p, R[1] * zi * zi * zi % c.p)
 
 
 def on_curve(c: Curve, P) -> bool:

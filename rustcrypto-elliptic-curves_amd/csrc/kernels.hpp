@@ -1,0 +1,289 @@
+// Batch kernels, written once over the curve traits (traits.hpp).
+//
+// HBM layout: the wire format itself (canonical big-endian bytes, array of structures).  One
+// element per lane; a lane reads its NB-byte operands with dword loads and byte-swaps them in
+// registers.  The hot kernels do >10^5 VALU instructions per 100-250 bytes moved, so the I/O
+// pattern is irrelevant to throughput (algorithmic HBM traffic is <0.3 % of the roofline, see
+// DESIGN.md); what matters is VGPR pressure and instruction count.
+#pragma once
+#include "traits.hpp"
+
+namespace ecgpu {
+
+#define ECGPU_GRID_STRIDE(i, n) \
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
+
+enum { FE_MUL = 0, FE_SQR = 1, FE_ADD = 2, FE_SUB = 3, FE_NEG = 4, FE_INV = 5, FE_SQRT = 6 };
+enum { PT_ADD = 0, PT_ADD_MIXED = 1, PT_DOUBLE = 2 };
+enum { FMT_AFFINE = 0, FMT_PROJECTIVE = 1 };
+
+template <class C>
+__device__ __forceinline__ void load_affine(typename C::Af& a, const u32* xy) {
+  C::fe_load(a.x, xy);
+  C::fe_load(a.y, xy + C::NW);
+  u32 z = 0;
+#pragma unroll
+  for (int i = 0; i < 2 * C::NW; i++) z |= xy[i];
+  a.inf = (z == 0) ? 1u : 0u;
+}
+template <class C>
+__device__ __forceinline__ void load_point(typename C::Pt& p, const u32* src, int fmt) {
+  if (fmt == FMT_PROJECTIVE) {
+    C::fe_load(p.x, src);
+    C::fe_load(p.y, src + C::NW);
+    C::fe_load(p.z, src + 2 * C::NW);
+  } else {
+    typename C::Af a;
+    load_affine<C>(a, src);
+    typename C::Pt id;
+    C::pt_identity(id);
+    typename C::Fe one;
+    C::fe_one(one);
+    C::fe_select(p.x, a.inf != 0, id.x, a.x);
+    C::fe_select(p.y, a.inf != 0, id.y, a.y);
+    C::fe_select(p.z, a.inf != 0, id.z, one);
+  }
+}
+template <class C>
+__device__ __forceinline__ void store_projective(u32* dst, const typename C::Pt& p) {
+  C::fe_store(dst, p.x);
+  C::fe_store(dst + C::NW, p.y);
+  C::fe_store(dst + 2 * C::NW, p.z);
+}
+// projective -> affine with one inversion in this lane (to_affine, k256 projective.rs:73-84)
+template <class C>
+__device__ __forceinline__ void store_affine_from_projective(u32* dst_xy, uint8_t* dst_inf, const typename C::Pt& p) {
+  typename C::Fe zi, x, y, zero;
+  const bool inf = C::fe_is_zero(p.z);
+  C::fe_inv(zi, p.z);
+  C::fe_mul(x, p.x, zi);
+  C::fe_mul(y, p.y, zi);
+  C::fe_zero(zero);
+  C::fe_select(x, inf, zero, x);
+  C::fe_select(y, inf, zero, y);
+  C::fe_store(dst_xy, x);
+  C::fe_store(dst_xy + C::NW, y);
+  if (dst_inf) *dst_inf = inf ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <class C, int OP>
+__global__ void __launch_bounds__(256) field_op_kernel(const u32* a, const u32* b, u32* out, size_t n) {
+  ECGPU_GRID_STRIDE(i, n) {
+    typename C::Fe x, y, r;
+    C::fe_load(x, a + i * C::NW);
+    if (OP == FE_MUL || OP == FE_ADD || OP == FE_SUB) C::fe_load(y, b + i * C::NW);
+    bool ok = true;
+    if (OP == FE_MUL) C::fe_mul(r, x, y);
+    if (OP == FE_SQR) C::fe_sqr(r, x);
+    if (OP == FE_ADD) C::fe_add(r, x, y);
+    if (OP == FE_SUB) C::fe_sub(r, x, y);
+    if (OP == FE_NEG) C::fe_neg(r, x);
+    if (OP == FE_INV) C::fe_inv(r, x);
+    if (OP == FE_SQRT) ok = C::fe_sqrt(r, x);
+    u32* o = out + i * C::NW;
+    C::fe_store(o, r);
+    if (!ok) {
+#pragma unroll
+      for (int j = 0; j < C::NW; j++) o[j] = 0xFFFFFFFFu;
+    }
+  }
+}
+
+template <class C, int OP>
+__global__ void __launch_bounds__(256) point_op_kernel(const u32* p, const u32* q, u32* out, size_t n) {
+  ECGPU_GRID_STRIDE(i, n) {
+    typename C::Pt a, r;
+    load_point<C>(a, p + i * 3 * C::NW, FMT_PROJECTIVE);
+    if (OP == PT_ADD) {
+      typename C::Pt b;
+      load_point<C>(b, q + i * 3 * C::NW, FMT_PROJECTIVE);
+      C::pt_add(r, a, b);
+    }
+    if (OP == PT_ADD_MIXED) {
+      typename C::Af b;
+      load_affine<C>(b, q + i * 2 * C::NW);
+      C::pt_add_mixed(r, a, b);
+    }
+    if (OP == PT_DOUBLE) C::pt_double(r, a);
+    store_projective<C>(out + i * 3 * C::NW, r);
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) normalize_kernel(const u32* p, u32* out_xy, uint8_t* out_inf, size_t n) {
+  ECGPU_GRID_STRIDE(i, n) {
+    typename C::Pt a;
+    load_point<C>(a, p + i * 3 * C::NW, FMT_PROJECTIVE);
+    store_affine_from_projective<C>(out_xy + i * 2 * C::NW, out_inf ? out_inf + i : nullptr, a);
+  }
+}
+
+// Reference-faithful n independent linear combinations of NT terms (NT = 1 is `&P * &k`).
+template <class C, int NT>
+__global__ void __launch_bounds__(256) lincomb_ref_kernel(const u32* scalars, const u32* points, int pt_fmt,
+                                                          u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
+  typename C::Pt tab[C::REF_TABLE_PTS * NT];
+  ECGPU_GRID_STRIDE(i, n) {
+    typename C::Pt pts[NT], r;
+    u32 ks[NT][C::NW];
+    const int pw = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * C::NW;
+#pragma unroll 1
+    for (int t = 0; t < NT; t++) {
+      C::scalar_load(ks[t], scalars + (i * NT + t) * C::NW);
+      load_point<C>(pts[t], points + (i * NT + t) * pw, pt_fmt);
+    }
+    C::template lincomb_ref<NT>(r, pts, ks, tab);
+    if (out_fmt == FMT_PROJECTIVE) store_projective<C>(out + i * 3 * C::NW, r);
+    else store_affine_from_projective<C>(out + i * 2 * C::NW, out_inf ? out_inf + i : nullptr, r);
+  }
+}
+
+template <class C>
+__global__ void gen_table_kernel(typename C::Pt* tab) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) C::gen_table_build(tab);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) mul_gen_ref_kernel(const u32* scalars, const typename C::Pt* gen_tab, u32* out,
+                                                          int out_fmt, uint8_t* out_inf, size_t n) {
+  ECGPU_GRID_STRIDE(i, n) {
+    u32 k[C::NW];
+    C::scalar_load(k, scalars + i * C::NW);
+    typename C::Pt r;
+    C::mul_gen_ref(r, k, gen_tab);
+    if (out_fmt == FMT_PROJECTIVE) store_projective<C>(out + i * 3 * C::NW, r);
+    else store_affine_from_projective<C>(out + i * 2 * C::NW, out_inf ? out_inf + i : nullptr, r);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(256) validate_scalars_kernel(const u32* scalars, uint8_t* ok, size_t n) {
+  ECGPU_GRID_STRIDE(i, n) {
+    u32 k[C::NW], o[C::NW];
+    C::scalar_load(k, scalars + i * C::NW);
+    C::order(o);
+    ok[i] = mp_geq<C::NW>(k, o) ? 0 : 1;
+  }
+}
+template <class C>
+__global__ void __launch_bounds__(256) validate_points_kernel(const u32* xy, uint8_t* ok, size_t n) {
+  ECGPU_GRID_STRIDE(i, n) {
+    const u32* src = xy + i * 2 * C::NW;
+    u32 raw[2 * C::NW];
+    u32 z = 0;
+#pragma unroll
+    for (int j = 0; j < 2 * C::NW; j++) { raw[j] = src[j]; z |= raw[j]; }
+    typename C::Fe x, y, l, r;
+    // canonical-range check must look at the raw integers, before any domain conversion
+    bool canon = true;
+    {
+      u32 lx[C::NW], ly[C::NW], p[C::NW];
+      words_load_be<C::NW>(lx, raw);
+      words_load_be<C::NW>(ly, raw + C::NW);
+      C::modulus(p);
+      canon = !mp_geq<C::NW>(lx, p) && !mp_geq<C::NW>(ly, p);
+    }
+    C::fe_load(x, raw);
+    C::fe_load(y, raw + C::NW);
+    C::fe_sqr(l, y);
+    C::curve_rhs(r, x);
+    typename C::Fe d;
+    C::fe_sub(d, l, r);
+    ok[i] = (z == 0) || (canon && C::fe_is_zero(d)) ? 1 : 0;
+  }
+}
+template <class C>
+__global__ void __launch_bounds__(256) decompress_kernel(const u32* xs, const uint8_t* y_is_odd, u32* out_xy, uint8_t* ok, size_t n) {
+  ECGPU_GRID_STRIDE(i, n) {
+    u32 raw[C::NW], lx[C::NW], p[C::NW];
+#pragma unroll
+    for (int j = 0; j < C::NW; j++) raw[j] = xs[i * C::NW + j];
+    words_load_be<C::NW>(lx, raw);
+    C::modulus(p);
+    const bool canon = !mp_geq<C::NW>(lx, p);
+    typename C::Fe x, rhs, y, ny;
+    C::fe_load(x, raw);
+    C::curve_rhs(rhs, x);
+    const bool has = C::fe_sqrt(y, rhs);
+    C::fe_neg(ny, y);
+    const bool odd = C::fe_is_odd(y);
+    C::fe_select(y, odd == ((y_is_odd[i] & 1) != 0), y, ny);
+    const bool good = canon && has;
+    u32* o = out_xy + i * 2 * C::NW;
+    typename C::Fe zero;
+    C::fe_zero(zero);
+    C::fe_select(x, good, x, zero);
+    C::fe_select(y, good, y, zero);
+    C::fe_store(o, x);
+    C::fe_store(o + C::NW, y);
+    ok[i] = good ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic inputs (oracle/synth.py is the specification)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 synth_word(u64 seed, u64 stream, u64 index, u32 j) {
+  u64 z = (seed ^ (stream * 0xD1342543DE82EF95ull)) + (8 * index + j + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// value as little-endian 32-bit limbs (word 0 of the stream is the most significant)
+template <int NW>
+__device__ __forceinline__ void synth_value(u32* limbs, u64 seed, u64 stream, u64 index) {
+#pragma unroll
+  for (int j = 0; j < NW / 2; j++) {
+    const u64 w = synth_word(seed, stream, index, j);
+    limbs[NW - 1 - 2 * j] = (u32)(w >> 32);
+    limbs[NW - 2 - 2 * j] = (u32)w;
+  }
+}
+template <int NW>
+__device__ __forceinline__ void reduce_once(u32* v, const u32* m) {
+  u32 t[NW];
+  const u32 bw = mp_sub<NW>(t, v, m);
+#pragma unroll
+  for (int i = 0; i < NW; i++) v[i] = bw ? v[i] : t[i];
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) synth_scalars_kernel(u64 seed, u64 first, u32* out, size_t n) {
+  ECGPU_GRID_STRIDE(i, n) {
+    u32 v[C::NW], o[C::NW];
+    synth_value<C::NW>(v, seed, 0, first + i);
+    C::order(o);
+    reduce_once<C::NW>(v, o);
+    words_store_be<C::NW>(out + i * C::NW, v);
+  }
+}
+template <class C>
+__global__ void __launch_bounds__(256) synth_points_kernel(u64 seed, u64 first, u32* out_xy, size_t n) {
+  ECGPU_GRID_STRIDE(i, n) {
+    typename C::Fe x, y, ny, rhs;
+    bool found = false;
+    for (int t = 0; t < 64 && !found; t++) {
+      u32 v[C::NW], p[C::NW], be[C::NW];
+      synth_value<C::NW>(v, seed, 1 + t, first + i);
+      C::modulus(p);
+      reduce_once<C::NW>(v, p);
+      const u32 want_odd = (u32)synth_word(seed, 1 + t, first + i, 7) & 1u;
+      words_store_be<C::NW>(be, v);
+      C::fe_load(x, be);
+      C::curve_rhs(rhs, x);
+      if (C::fe_sqrt(y, rhs)) {
+        C::fe_neg(ny, y);
+        const bool odd = C::fe_is_odd(y);
+        C::fe_select(y, odd == (want_odd != 0), y, ny);
+        found = true;
+      }
+    }
+    u32* o = out_xy + i * 2 * C::NW;
+    C::fe_store(o, x);
+    C::fe_store(o + C::NW, y);
+  }
+}
+
+}  // namespace ecgpu

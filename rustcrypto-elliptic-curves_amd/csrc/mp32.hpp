@@ -1,0 +1,219 @@
+// Multi-precision primitives on saturated 32-bit limbs for gfx950.
+//
+// Design notes (measured with tools/ubench/valu_rates.hip on MI355X):
+//  * the native integer multiplier is v_mad_u64_u32 (32x32+64 -> 64, carry-out in an SGPR pair);
+//    a u64 x u64 product lowers to four of them, so the natural limb is 32 bits and a field
+//    element of a 256-bit (384-bit) prime lives in 8 (12) VGPRs of one lane;
+//  * v_mad_u64_u32 has a carry-out but no carry-in and 64-bit VGPR operands must be even aligned,
+//    so products are accumulated column-wise into a 96-bit accumulator: one mad plus one
+//    v_addc_co_u32 per 32x32 multiply-accumulate.  hipcc does not form that pair from C++
+//    (it emits mad + 64-bit add + compare + select), hence the two-instruction asm statement.
+//
+// Everything here is __host__ __device__: the same templates are compiled by the host compiler
+// into tests/hosttwin (a test-only library) so that the arithmetic can be checked against the
+// oracle in a container without a GPU.  The shipped library (libecgpu.so) only ever launches
+// the device instantiation.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ECGPU_HD __host__ __device__ __forceinline__
+#else
+#define ECGPU_HD inline __attribute__((always_inline))
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ECGPU_ASM 1
+#else
+#define ECGPU_ASM 0
+#endif
+
+namespace ecgpu {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---------------------------------------------------------------------------------------------
+// carry chains.  __builtin_addc / __builtin_subc lower to v_add_co_u32 / v_addc_co_u32 chains.
+// ---------------------------------------------------------------------------------------------
+ECGPU_HD u32 addc(u32 a, u32 b, u32& carry) {
+#if defined(__clang__)
+  u32 co;
+  u32 r = __builtin_addc(a, b, carry, &co);
+  carry = co;
+  return r;
+#else
+  u64 t = (u64)a + b + carry;
+  carry = (u32)(t >> 32);
+  return (u32)t;
+#endif
+}
+ECGPU_HD u32 subb(u32 a, u32 b, u32& borrow) {
+#if defined(__clang__)
+  u32 bo;
+  u32 r = __builtin_subc(a, b, borrow, &bo);
+  borrow = bo;
+  return r;
+#else
+  u64 t = (u64)a - b - borrow;
+  borrow = (u32)(t >> 63);
+  return (u32)t;
+#endif
+}
+
+// r = a + b, returns carry-out
+template <int N>
+ECGPU_HD u32 mp_add(u32* r, const u32* a, const u32* b) {
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = addc(a[i], b[i], c);
+  return c;
+}
+// r = a - b, returns borrow-out
+template <int N>
+ECGPU_HD u32 mp_sub(u32* r, const u32* a, const u32* b) {
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = subb(a[i], b[i], c);
+  return c;
+}
+// a >= b ?
+template <int N>
+ECGPU_HD bool mp_geq(const u32* a, const u32* b) {
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) (void)subb(a[i], b[i], c);
+  return c == 0;
+}
+template <int N>
+ECGPU_HD bool mp_is_zero(const u32* a) {
+  u32 t = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) t |= a[i];
+  return t == 0;
+}
+template <int N>
+ECGPU_HD bool mp_eq(const u32* a, const u32* b) {
+  u32 t = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) t |= a[i] ^ b[i];
+  return t == 0;
+}
+template <int N>
+ECGPU_HD void mp_copy(u32* r, const u32* a) {
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = a[i];
+}
+template <int N>
+ECGPU_HD void mp_zero(u32* r) {
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = 0;
+}
+// r = cond ? a : b   (lane-wise select, v_cndmask_b32)
+template <int N>
+ECGPU_HD void mp_select(u32* r, bool cond, const u32* a, const u32* b) {
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = cond ? a[i] : b[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// 96-bit column accumulator
+// ---------------------------------------------------------------------------------------------
+struct Acc96 {
+  u64 lo;
+  u32 hi;
+};
+
+// c += a * b
+ECGPU_HD void mac(Acc96& c, u32 a, u32 b) {
+#if ECGPU_ASM
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(c.lo), "+v"(c.hi)
+      : "v"(a), "v"(b)
+      : "vcc");
+#else
+  u64 p = (u64)a * b;
+  c.lo += p;
+  c.hi += (c.lo < p);
+#endif
+}
+// c += a * b where the caller guarantees the low 64 bits cannot overflow
+ECGPU_HD void mac_nc(Acc96& c, u32 a, u32 b) { c.lo += (u64)a * b; }
+// c += 2 * a * b
+ECGPU_HD void mac2(Acc96& c, u32 a, u32 b) {
+  mac(c, a, b);
+  mac(c, a, b);
+}
+// c += w (a 32-bit word)
+ECGPU_HD void acc_add32(Acc96& c, u32 w) {
+#if ECGPU_ASM
+  // a*1 + c: one mad + one addc, cheaper than a three-instruction carry chain
+  asm("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(c.lo), "+v"(c.hi)
+      : "v"(w)
+      : "vcc");
+#else
+  c.lo += w;
+  c.hi += (c.lo < w);
+#endif
+}
+// pop the low word and shift the accumulator down by 32 bits
+ECGPU_HD u32 acc_pop(Acc96& c) {
+  u32 r = (u32)c.lo;
+  c.lo = (c.lo >> 32) | ((u64)c.hi << 32);
+  c.hi = 0;
+  return r;
+}
+
+// r[0..2N) = a * b   (schoolbook, product scanning)
+template <int N>
+ECGPU_HD void mp_mul_wide(u32* r, const u32* a, const u32* b) {
+  Acc96 c{0, 0};
+#pragma unroll
+  for (int k = 0; k < 2 * N - 1; k++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < N) {
+        if (k == 0 || k == 2 * N - 2) mac_nc(c, a[i], b[j]); else mac(c, a[i], b[j]);
+      }
+    }
+    r[k] = acc_pop(c);
+  }
+  r[2 * N - 1] = (u32)c.lo;
+}
+
+// r[0..2N) = a * a : off-diagonal products once, doubled by a one-bit funnel shift, plus the squares
+template <int N>
+ECGPU_HD void mp_sqr_wide(u32* r, const u32* a) {
+  u32 x[2 * N];
+  Acc96 c{0, 0};
+  x[0] = 0;
+#pragma unroll
+  for (int k = 1; k < 2 * N - 2; k++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int j = k - i;
+      if (j > i && j < N) mac(c, a[i], a[j]);
+    }
+    x[k] = acc_pop(c);
+  }
+  x[2 * N - 2] = (u32)c.lo;   // the cross sum is < 2^(64N-1): it fits, top bit clear
+  x[2 * N - 1] = (u32)(c.lo >> 32);
+  // r = 2*x + sum a_i^2 2^(64 i)
+  u32 carry = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const u64 d = (u64)a[i] * a[i];
+    const u32 lo2 = (x[2 * i] << 1) | (i ? (x[2 * i - 1] >> 31) : 0);
+    const u32 hi2 = (x[2 * i + 1] << 1) | (x[2 * i] >> 31);
+    r[2 * i] = addc(lo2, (u32)d, carry);
+    r[2 * i + 1] = addc(hi2, (u32)(d >> 32), carry);
+  }
+}
+
+// byte order helpers: canonical wire format is big-endian (to_bytes / to_repr of the reference)
+ECGPU_HD u32 bswap32(u32 x) { return __builtin_bswap32(x); }
+
+}  // namespace ecgpu

@@ -1,0 +1,273 @@
+"""Host-side mirror of the reference's trait surface over the libecgpu C ABI (include/ecgpu.h).
+
+The reference is a Rust workspace; no Rust toolchain exists in this image, so the host side
+above the C ABI that tests and bench.py drive is this thin ctypes binding.  Names follow the
+reference: `Curve.mul_by_generator` (MulByGenerator), `Curve.mul` (`&P * &k`), `Curve.lincomb`
+(LinearCombination), `Curve.add / add_mixed / double` (ProjectivePoint), `Curve.batch_normalize`
+(BatchNormalize), `Curve.field_*` (FieldElement).  The Rust shim that a maintainer would add is
+in ../rust/ (source only) and described in INTEGRATION.md.
+
+There is no CPU fallback: if libecgpu.so is missing or no gfx950 device is present, every entry
+point raises `EcgpuError`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+HOST, DEVICE = 0, 1
+AFFINE, PROJECTIVE = 0, 1
+EXACT_REFERENCE = 1
+K256, P256, P384 = 0, 1, 2
+CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384}
+FIELD_BYTES = {K256: 32, P256: 32, P384: 48}
+FE_MUL, FE_SQR, FE_ADD, FE_SUB, FE_NEG, FE_INV, FE_SQRT = range(7)
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libecgpu.so")
+
+
+class EcgpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen libecgpu.so and declare every prototype of include/ecgpu.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise EcgpuError(f"{p} not found: build it with `make -C rustcrypto-elliptic-curves_amd` (no CPU fallback exists)")
+    lib = ctypes.CDLL(p)
+    vp, sz, i, u8p = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p
+    lib.ecgpu_create.argtypes = [ctypes.POINTER(vp), i]
+    lib.ecgpu_destroy.argtypes = [vp]
+    lib.ecgpu_destroy.restype = None
+    lib.ecgpu_set_stream.argtypes = [vp, vp]
+    lib.ecgpu_synchronize.argtypes = [vp]
+    lib.ecgpu_last_error.argtypes = [vp]
+    lib.ecgpu_last_error.restype = ctypes.c_char_p
+    lib.ecgpu_version.restype = ctypes.c_char_p
+    lib.ecgpu_field_bytes.argtypes = [i]
+    lib.ecgpu_field_bytes.restype = sz
+    lib.ecgpu_timer_start.argtypes = [vp]
+    lib.ecgpu_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.ecgpu_field_op_batch.argtypes = [vp, i, i, u8p, u8p, u8p, sz, i]
+    lib.ecgpu_point_add_batch.argtypes = [vp, i, u8p, u8p, u8p, sz, i]
+    lib.ecgpu_point_add_mixed_batch.argtypes = [vp, i, u8p, u8p, u8p, sz, i]
+    lib.ecgpu_point_double_batch.argtypes = [vp, i, u8p, u8p, sz, i]
+    lib.ecgpu_batch_normalize.argtypes = [vp, i, u8p, u8p, u8p, sz, i]
+    lib.ecgpu_mul_batch.argtypes = [vp, i, u8p, u8p, i, u8p, i, u8p, sz, i, ctypes.c_uint]
+    lib.ecgpu_lincomb_batch.argtypes = [vp, i, u8p, u8p, i, sz, u8p, i, u8p, sz, i, ctypes.c_uint]
+    lib.ecgpu_msm.argtypes = [vp, i, u8p, u8p, i, sz, u8p, i, i]
+    lib.ecgpu_validate_scalars.argtypes = [vp, i, u8p, u8p, sz, i]
+    lib.ecgpu_validate_points.argtypes = [vp, i, u8p, u8p, sz, i]
+    lib.ecgpu_decompress_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i]
+    lib.ecgpu_synth_scalars.argtypes = [vp, i, ctypes.c_uint64, ctypes.c_uint64, u8p, sz]
+    lib.ecgpu_synth_points.argtypes = [vp, i, ctypes.c_uint64, ctypes.c_uint64, u8p, sz]
+    for name in ("ecgpu_create", "ecgpu_set_stream", "ecgpu_synchronize", "ecgpu_timer_start", "ecgpu_timer_stop",
+                 "ecgpu_field_op_batch", "ecgpu_point_add_batch", "ecgpu_point_add_mixed_batch",
+                 "ecgpu_point_double_batch", "ecgpu_batch_normalize", "ecgpu_mul_batch", "ecgpu_lincomb_batch",
+                 "ecgpu_msm", "ecgpu_validate_scalars", "ecgpu_validate_points", "ecgpu_decompress_batch",
+                 "ecgpu_synth_scalars", "ecgpu_synth_points"):
+        getattr(lib, name).restype = ctypes.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "ecgpu_create", "ecgpu_destroy", "ecgpu_set_stream", "ecgpu_synchronize", "ecgpu_last_error", "ecgpu_version",
+    "ecgpu_field_bytes", "ecgpu_timer_start", "ecgpu_timer_stop", "ecgpu_field_op_batch", "ecgpu_point_add_batch",
+    "ecgpu_point_add_mixed_batch", "ecgpu_point_double_batch", "ecgpu_batch_normalize", "ecgpu_mul_batch",
+    "ecgpu_lincomb_batch", "ecgpu_msm", "ecgpu_validate_scalars", "ecgpu_validate_points", "ecgpu_decompress_batch",
+    "ecgpu_synth_scalars", "ecgpu_synth_points",
+)
+
+
+def _ptr(x):
+    """Host numpy array / bytes -> (pointer, keepalive); torch CUDA tensor or int -> device pointer."""
+    if x is None:
+        return None, None
+    if isinstance(x, int):
+        return ctypes.c_void_p(x), None
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return ctypes.c_void_p(x.ctypes.data), x
+    if hasattr(x, "data_ptr"):  # torch tensor
+        return ctypes.c_void_p(x.data_ptr()), x
+    raise TypeError(type(x))
+
+
+class Context:
+    """One context per device (include/ecgpu.h: context section)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.handle = ctypes.c_void_p()
+        rc = self.lib.ecgpu_create(ctypes.byref(self.handle), device)
+        if rc != 0:
+            raise EcgpuError(f"ecgpu_create(device={device}) failed with {rc} (no usable gfx950 GPU? there is no CPU fallback)")
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            self.lib.ecgpu_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise EcgpuError(f"ecgpu error {rc}: {self.lib.ecgpu_last_error(self.handle).decode()}")
+
+    def set_stream(self, stream_handle: int):
+        self.check(self.lib.ecgpu_set_stream(self.handle, ctypes.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self.check(self.lib.ecgpu_synchronize(self.handle))
+
+    def timer_start(self):
+        self.check(self.lib.ecgpu_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = ctypes.c_float()
+        self.check(self.lib.ecgpu_timer_stop(self.handle, ctypes.byref(ms)))
+        return ms.value
+
+    def curve(self, name_or_id) -> "Curve":
+        cid = CURVE_IDS[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+        return Curve(self, cid)
+
+
+def _host_out(n: int, width: int) -> np.ndarray:
+    return np.zeros((n, width), dtype=np.uint8)
+
+
+def _as_host(x, width: int) -> np.ndarray:
+    """bytes / list of bytes / ndarray -> (n, width) uint8."""
+    if isinstance(x, np.ndarray):
+        a = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, width)
+    elif isinstance(x, (bytes, bytearray)):
+        a = np.frombuffer(bytes(x), dtype=np.uint8).reshape(-1, width).copy()
+    else:
+        a = np.frombuffer(b"".join(x), dtype=np.uint8).reshape(-1, width).copy()
+    return a
+
+
+class Curve:
+    """Batch versions of the reference's per-curve arithmetic surface.
+
+    Host-memory methods take/return numpy uint8 arrays shaped (n, bytes) in the canonical
+    big-endian wire format; the `*_device` methods take raw device pointers / torch tensors and
+    are asynchronous on the context stream."""
+
+    def __init__(self, ctx: Context, cid: int):
+        self.ctx, self.id, self.nb = ctx, cid, FIELD_BYTES[cid]
+
+    # --- FieldElement -----------------------------------------------------------------------
+    def field_op(self, op: int, a, b=None) -> np.ndarray:
+        a = _as_host(a, self.nb)
+        bb = _as_host(b, self.nb) if b is not None else None
+        out = _host_out(len(a), self.nb)
+        pa, _ = _ptr(a); pb, _ = _ptr(bb); po, _ = _ptr(out)
+        self.ctx.check(self.ctx.lib.ecgpu_field_op_batch(self.ctx.handle, self.id, op, pa, pb, po, len(a), HOST))
+        return out
+
+    # --- ProjectivePoint::{add, add_mixed, double}, BatchNormalize ------------------------------
+    def add(self, p_xyz, q_xyz) -> np.ndarray:
+        p, q = _as_host(p_xyz, 3 * self.nb), _as_host(q_xyz, 3 * self.nb)
+        out = _host_out(len(p), 3 * self.nb)
+        self.ctx.check(self.ctx.lib.ecgpu_point_add_batch(self.ctx.handle, self.id, _ptr(p)[0], _ptr(q)[0], _ptr(out)[0], len(p), HOST))
+        return out
+
+    def add_mixed(self, p_xyz, q_xy) -> np.ndarray:
+        p, q = _as_host(p_xyz, 3 * self.nb), _as_host(q_xy, 2 * self.nb)
+        out = _host_out(len(p), 3 * self.nb)
+        self.ctx.check(self.ctx.lib.ecgpu_point_add_mixed_batch(self.ctx.handle, self.id, _ptr(p)[0], _ptr(q)[0], _ptr(out)[0], len(p), HOST))
+        return out
+
+    def double(self, p_xyz) -> np.ndarray:
+        p = _as_host(p_xyz, 3 * self.nb)
+        out = _host_out(len(p), 3 * self.nb)
+        self.ctx.check(self.ctx.lib.ecgpu_point_double_batch(self.ctx.handle, self.id, _ptr(p)[0], _ptr(out)[0], len(p), HOST))
+        return out
+
+    def batch_normalize(self, p_xyz):
+        p = _as_host(p_xyz, 3 * self.nb)
+        out, inf = _host_out(len(p), 2 * self.nb), np.zeros(len(p), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ecgpu_batch_normalize(self.ctx.handle, self.id, _ptr(p)[0], _ptr(out)[0], _ptr(inf)[0], len(p), HOST))
+        return out, inf
+
+    # --- Mul<Scalar>, MulByGenerator, LinearCombination -----------------------------------------
+    def lincomb(self, scalars, points, terms: int = 1, point_format: int = AFFINE, out_format: int = AFFINE, flags: int = 0):
+        s = _as_host(scalars, self.nb)
+        n = len(s) // terms
+        pw = (3 if point_format == PROJECTIVE else 2) * self.nb
+        ow = (3 if out_format == PROJECTIVE else 2) * self.nb
+        p = _as_host(points, pw) if points is not None else None
+        out, inf = _host_out(n, ow), np.zeros(n, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ecgpu_lincomb_batch(self.ctx.handle, self.id, _ptr(s)[0], _ptr(p)[0], point_format, terms,
+                                                        _ptr(out)[0], out_format, _ptr(inf)[0], n, HOST, flags))
+        return (out, inf) if out_format == AFFINE else out
+
+    def mul(self, scalars, points, point_format: int = AFFINE, out_format: int = AFFINE, flags: int = 0):
+        return self.lincomb(scalars, points, 1, point_format, out_format, flags)
+
+    def mul_by_generator(self, scalars, out_format: int = AFFINE, flags: int = 0):
+        return self.lincomb(scalars, None, 1, AFFINE, out_format, flags)
+
+    def mul_device(self, d_scalars, d_points, d_out, n: int, point_format: int = AFFINE, out_format: int = AFFINE,
+                   d_out_inf=None, flags: int = 0):
+        self.ctx.check(self.ctx.lib.ecgpu_mul_batch(self.ctx.handle, self.id, _ptr(d_scalars)[0], _ptr(d_points)[0], point_format,
+                                                    _ptr(d_out)[0], out_format, _ptr(d_out_inf)[0], n, DEVICE, flags))
+
+    def msm(self, scalars, points, point_format: int = AFFINE, out_format: int = AFFINE) -> np.ndarray:
+        s = _as_host(scalars, self.nb)
+        pw = (3 if point_format == PROJECTIVE else 2) * self.nb
+        p = _as_host(points, pw)
+        out = _host_out(1, (3 if out_format == PROJECTIVE else 2) * self.nb)
+        self.ctx.check(self.ctx.lib.ecgpu_msm(self.ctx.handle, self.id, _ptr(s)[0], _ptr(p)[0], point_format, len(s), _ptr(out)[0], out_format, HOST))
+        return out[0]
+
+    def msm_device(self, d_scalars, d_points, n: int, d_out, point_format: int = AFFINE, out_format: int = AFFINE):
+        self.ctx.check(self.ctx.lib.ecgpu_msm(self.ctx.handle, self.id, _ptr(d_scalars)[0], _ptr(d_points)[0], point_format, n,
+                                              _ptr(d_out)[0], out_format, DEVICE))
+
+    # --- decoding ---------------------------------------------------------------------------------
+    def validate_scalars(self, scalars) -> np.ndarray:
+        s = _as_host(scalars, self.nb)
+        ok = np.zeros(len(s), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ecgpu_validate_scalars(self.ctx.handle, self.id, _ptr(s)[0], _ptr(ok)[0], len(s), HOST))
+        return ok
+
+    def validate_points(self, points_xy) -> np.ndarray:
+        p = _as_host(points_xy, 2 * self.nb)
+        ok = np.zeros(len(p), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ecgpu_validate_points(self.ctx.handle, self.id, _ptr(p)[0], _ptr(ok)[0], len(p), HOST))
+        return ok
+
+    def decompress(self, xs, y_is_odd):
+        x = _as_host(xs, self.nb)
+        odd = np.ascontiguousarray(y_is_odd, dtype=np.uint8)
+        out, ok = _host_out(len(x), 2 * self.nb), np.zeros(len(x), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ecgpu_decompress_batch(self.ctx.handle, self.id, _ptr(x)[0], _ptr(odd)[0], _ptr(out)[0], _ptr(ok)[0], len(x), HOST))
+        return out, ok
+
+    # --- synthetic inputs (device buffers) ---------------------------------------------------------
+    def synth_scalars_device(self, d_out, n: int, seed: int, first_index: int = 0):
+        self.ctx.check(self.ctx.lib.ecgpu_synth_scalars(self.ctx.handle, self.id, seed, first_index, _ptr(d_out)[0], n))
+
+    def synth_points_device(self, d_out, n: int, seed: int, first_index: int = 0):
+        self.ctx.check(self.ctx.lib.ecgpu_synth_points(self.ctx.handle, self.id, seed, first_index, _ptr(d_out)[0], n))

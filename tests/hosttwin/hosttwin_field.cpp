@@ -1,0 +1,36 @@
+// TEST-ONLY host build of the device arithmetic templates (csrc/*.hpp).
+// Lets the CPU test-suite check the exact code that the HIP kernels instantiate against the
+// oracle in a container without a GPU.  Never linked into libecgpu.so.
+#include <string.h>
+#include "fe_k256.hpp"
+using namespace ecgpu;
+
+static void load(FeK256& f, const uint8_t* b) { u32 w[8]; memcpy(w, b, 32); k256::from_be_words(f, w); }
+static void store(uint8_t* b, const FeK256& f) { u32 w[8]; k256::to_be_words(w, f); memcpy(b, w, 32); }
+
+extern "C" {
+// op: 0 mul 1 sqr 2 add 3 sub 4 neg 5 inv 6 sqrt 7 mul_small(b[0..3] LE) 8 normalize-only
+// raw=1: inputs are taken as raw 256-bit integers (possibly >= p) and the output is NOT normalised
+int ht_k256_fe_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int raw) {
+  for (int i = 0; i < n; i++) {
+    FeK256 x, y, r; load(x, a + 32 * i); if (b) load(y, b + 32 * i);
+    int ok = 1;
+    switch (op) {
+      case 0: k256::mul(r, x, y); break;
+      case 1: k256::sqr(r, x); break;
+      case 2: k256::add(r, x, y); break;
+      case 3: k256::sub(r, x, y); break;
+      case 4: k256::neg(r, x); break;
+      case 5: k256::inv(r, x); break;
+      case 6: ok = k256::sqrt(r, x); break;
+      case 7: { u32 k; memcpy(&k, b + 32 * i + 28, 4); k256::mul_small(r, x, bswap32(k)); break; }
+      case 8: r = x; break;
+      default: return -1;
+    }
+    if (!raw) k256::normalize(r, r);
+    store(out + 32 * i, r);
+    if (op == 6 && !ok) memset(out + 32 * i, 0xFF, 32);
+  }
+  return 0;
+}
+}

@@ -1,0 +1,225 @@
+"""GPU parity tests for k256 through the C ABI (libecgpu.so), against the oracle and the
+committed golden fixtures.  Bit-exact: integer arithmetic, canonical bytes."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import ecmodel as M
+from oracle import synth
+from conftest import load_config1
+
+pytestmark = pytest.mark.gpu
+
+C = M.K256
+N, P = C.n, C.p
+
+
+@pytest.fixture(scope="module")
+def curve():
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    yield ctx.curve("k256")
+    ctx.close()
+
+
+def fe_bytes(vals):
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "big") for v in vals), dtype=np.uint8).reshape(-1, 32).copy()
+
+
+def to_ints(arr):
+    return [int.from_bytes(bytes(r), "big") for r in arr]
+
+
+def proj_arr(pts):
+    return np.frombuffer(b"".join(M.proj_bytes(C, p) for p in pts), dtype=np.uint8).reshape(-1, 96).copy()
+
+
+def rand_proj(rng, n, start=0):
+    out = []
+    for i in range(n):
+        x, y = synth.point(C, start + i, seed=77)
+        z = rng.randrange(1, P)
+        out.append((x * z % P, y * z % P, z))
+    return out
+
+
+EDGE = [0, 1, 2, 977, 2**32 + 976, P - 2, P - 1, 2**255, 2**128 - 1, 2**32 - 1, 2**64]
+
+
+def test_field_ops(curve, ref_vectors):
+    import ecgpu
+    rng = random.Random(1)
+    xs = [a for a in EDGE for _ in EDGE] + [rng.randrange(P) for _ in range(4096)]
+    ys = [b for _ in EDGE for b in EDGE] + [rng.randrange(P) for _ in range(4096)]
+    a, b = fe_bytes(xs), fe_bytes(ys)
+    for op, fn in ((ecgpu.FE_MUL, lambda x, y: x * y), (ecgpu.FE_ADD, lambda x, y: x + y), (ecgpu.FE_SUB, lambda x, y: x - y)):
+        got = to_ints(curve.field_op(op, a, b))
+        assert got == [fn(x, y) % P for x, y in zip(xs, ys)]
+    assert to_ints(curve.field_op(ecgpu.FE_SQR, a)) == [x * x % P for x in xs]
+    assert to_ints(curve.field_op(ecgpu.FE_NEG, a)) == [(-x) % P for x in xs]
+    inv = to_ints(curve.field_op(ecgpu.FE_INV, a[:600]))
+    assert all((x == 0 and g == 0) or g * x % P == 1 for x, g in zip(xs, inv))
+    sq = to_ints(curve.field_op(ecgpu.FE_SQRT, a[:600]))
+    for x, g in zip(xs, sq):
+        want = M.field_sqrt(C, x)
+        assert g == (2**256 - 1 if want is None else want)
+    # reference KATs (field_8x32_risc0.rs:225-303, test_vectors/field.rs)
+    k = {n: int(v, 16) for n, v in ref_vectors["k256"]["field_kat"].items()}
+    assert to_ints(curve.field_op(ecgpu.FE_MUL, fe_bytes([k["a"]]), fe_bytes([k["b"]]))) == [k["mul"]]
+    assert to_ints(curve.field_op(ecgpu.FE_ADD, fe_bytes([k["a"]]), fe_bytes([k["b"]]))) == [k["add"]]
+    assert to_ints(curve.field_op(ecgpu.FE_SQR, fe_bytes([k["a"]]))) == [k["square_a"]]
+    assert to_ints(curve.field_op(ecgpu.FE_NEG, fe_bytes([k["a"]]))) == [k["negate_a"]]
+    dbl = [int(v, 16) for v in ref_vectors["k256"]["field_dbl"]]
+    assert to_ints(curve.field_op(ecgpu.FE_ADD, fe_bytes(dbl[:-1]), fe_bytes(dbl[:-1]))) == dbl[1:]
+
+
+def test_point_ops_exact_xyz(curve):
+    rng = random.Random(2)
+    ps = rand_proj(rng, 300) + [M.IDENTITY, C.G, M.point_neg(C, C.G), C.G, M.IDENTITY]
+    qs = rand_proj(rng, 300, start=1000) + [C.G, M.IDENTITY, C.G, C.G, M.IDENTITY]
+    got = curve.add(proj_arr(ps), proj_arr(qs))
+    assert bytes(got) == b"".join(M.proj_bytes(C, M.k256_add(p, q)) for p, q in zip(ps, qs))
+    got = curve.double(proj_arr(ps))
+    assert bytes(got) == b"".join(M.proj_bytes(C, M.k256_double(p)) for p in ps)
+    aff = [M.to_affine(C, q) for q in qs]
+    qa = np.frombuffer(b"".join(M.i2b(C, a[0]) + M.i2b(C, a[1]) for a in aff), dtype=np.uint8).reshape(-1, 64).copy()
+    got = curve.add_mixed(proj_arr(ps), qa)
+    assert bytes(got) == b"".join(M.proj_bytes(C, M.k256_add_mixed(p, a)) for p, a in zip(ps, aff))
+    xy, inf = curve.batch_normalize(proj_arr(ps))
+    for i, p in enumerate(ps):
+        assert bytes(xy[i]) + bytes([inf[i]]) == M.affine_bytes(C, M.to_affine(C, p))
+
+
+def test_group_vectors(curve, ref_vectors):
+    """ADD / MUL vectors of k256/src/test_vectors/group.rs through the GPU."""
+    import ecgpu
+    vec = ref_vectors["k256"]["group"]["mul"]
+    ks = fe_bytes([int(k, 16) for k, _, _ in vec])
+    want = b"".join(bytes.fromhex(x + y) for _, x, y in vec)
+    for flags in (0, ecgpu.EXACT_REFERENCE):
+        xy, inf = curve.mul_by_generator(ks, flags=flags)
+        assert bytes(xy) == want and not inf.any()
+        g = np.frombuffer(M.i2b(C, C.gx) + M.i2b(C, C.gy), dtype=np.uint8).reshape(1, 64).repeat(len(vec), 0).copy()
+        xy, inf = curve.mul(ks, g, flags=flags)
+        assert bytes(xy) == want and not inf.any()
+    # repeated addition of G (ADD_TEST_VECTORS) by mixed and full additions
+    add = ref_vectors["k256"]["group"]["add"]
+    acc = proj_arr([M.IDENTITY])
+    gp = proj_arr([C.G])
+    ga = np.frombuffer(M.i2b(C, C.gx) + M.i2b(C, C.gy), dtype=np.uint8).reshape(1, 64).copy()
+    accm = acc.copy()
+    for x, y in add:
+        acc = curve.add(acc, gp)
+        accm = curve.add_mixed(accm, ga)
+        for a in (acc, accm):
+            xy, inf = curve.batch_normalize(a)
+            assert bytes(xy[0]).hex() == (x + y).lower() and inf[0] == 0
+    # ECDSA d -> Q, k -> r
+    for v in ref_vectors["k256"]["ecdsa"]:
+        xy, _ = curve.mul_by_generator(fe_bytes([int(v["d"], 16), int(v["k"], 16)]))
+        assert bytes(xy[0]).hex() == v["q_x"] + v["q_y"]
+        assert int.from_bytes(bytes(xy[1][:32]), "big") % N == int(v["r"], 16)
+
+
+def test_hash2curve_add_triples(curve, ref_vectors):
+    for v in ref_vectors["k256"]["hash2curve"]:
+        q0 = (int(v["q0_x"], 16), int(v["q0_y"], 16), 1)
+        q1 = (int(v["q1_x"], 16), int(v["q1_y"], 16), 1)
+        xy, inf = curve.batch_normalize(curve.add(proj_arr([q0]), proj_arr([q1])))
+        assert bytes(xy[0]).hex() == v["p_x"] + v["p_y"]
+
+
+def test_config1_fixture_bit_exact(curve):
+    """BASELINE.json configs[0]: 1024 seeded (scalar, point) pairs, affine outputs byte for byte."""
+    import ecgpu
+    fx = load_config1("k256")
+    ks = np.frombuffer(b"".join(bytes.fromhex(r[0]) for r in fx["rows"]), dtype=np.uint8).reshape(-1, 32).copy()
+    pts = np.frombuffer(b"".join(bytes.fromhex(r[1] + r[2]) for r in fx["rows"]), dtype=np.uint8).reshape(-1, 64).copy()
+    want = b"".join(bytes.fromhex(r[3]) for r in fx["rows"])
+    for flags in (0, ecgpu.EXACT_REFERENCE):
+        xy, inf = curve.mul(ks, pts, flags=flags)
+        got = b"".join(bytes(xy[i]) + bytes([inf[i]]) for i in range(len(xy)))
+        assert got == want
+
+
+def test_mul_exact_reference_xyz_and_edges(curve):
+    import ecgpu
+    rng = random.Random(3)
+    ks = [0, 1, 2, N - 1, N - 2, (N - 1) // 2, 2**128 - 1, 2**128 + 1] * 3 + [rng.randrange(N) for _ in range(40)]
+    ps = [C.G] * 8 + [M.point_neg(C, C.G)] * 8 + [M.IDENTITY] * 8 + rand_proj(rng, 40, start=5000)
+    out = curve.mul(fe_bytes(ks), proj_arr(ps), point_format=ecgpu.PROJECTIVE, out_format=ecgpu.PROJECTIVE, flags=ecgpu.EXACT_REFERENCE)
+    for i, (p, k) in enumerate(zip(ps, ks)):
+        assert bytes(out[i]) == M.proj_bytes(C, M.k256_mul_ref(p, k)), i
+    # default schedule: the group element (affine) must match on the same edge inputs
+    xy, inf = curve.mul(fe_bytes(ks), proj_arr(ps), point_format=ecgpu.PROJECTIVE)
+    for i, (p, k) in enumerate(zip(ps, ks)):
+        want = M.affine_mul(C, k, M.to_affine_opt(C, p))
+        assert bytes(xy[i]) + bytes([inf[i]]) == M.affine_bytes(C, (0, 0, 1) if want is None else (want[0], want[1], 0)), i
+    # mul_by_generator exact XYZ
+    out = curve.mul_by_generator(fe_bytes(ks), out_format=ecgpu.PROJECTIVE, flags=ecgpu.EXACT_REFERENCE)
+    for i, k in enumerate(ks):
+        assert bytes(out[i]) == M.proj_bytes(C, M.k256_mul_by_generator_ref(k)), i
+
+
+def test_lincomb_two_terms(curve):
+    import ecgpu
+    rng = random.Random(4)
+    n = 64
+    ps = rand_proj(rng, 2 * n, start=9000)
+    ks = [rng.randrange(N) for _ in range(2 * n)]
+    out = curve.lincomb(fe_bytes(ks), proj_arr(ps), terms=2, point_format=ecgpu.PROJECTIVE, out_format=ecgpu.PROJECTIVE,
+                        flags=ecgpu.EXACT_REFERENCE)
+    for i in range(n):
+        want = M.k256_lincomb_ref([(ps[2 * i], ks[2 * i]), (ps[2 * i + 1], ks[2 * i + 1])])
+        assert bytes(out[i]) == M.proj_bytes(C, want)
+    xy, inf = curve.lincomb(fe_bytes(ks), proj_arr(ps), terms=2, point_format=ecgpu.PROJECTIVE)
+    for i in range(n):
+        a = M.affine_add(C, M.affine_mul(C, ks[2 * i], M.to_affine_opt(C, ps[2 * i])),
+                         M.affine_mul(C, ks[2 * i + 1], M.to_affine_opt(C, ps[2 * i + 1])))
+        assert bytes(xy[i]) == M.i2b(C, a[0]) + M.i2b(C, a[1])
+
+
+def test_validate_and_decompress(curve):
+    rng = random.Random(5)
+    sc = [0, 1, N - 1, N, N + 1, 2**256 - 1] + [rng.randrange(2**256) for _ in range(50)]
+    ok = curve.validate_scalars(fe_bytes(sc))
+    assert list(ok) == [1 if s < N else 0 for s in sc]
+    pts = [synth.point(C, i, seed=5) for i in range(20)]
+    bad = [(x, (y + 1) % P) for x, y in pts[:5]] + [(P, 1), (1, P + 5), (0, 0)]
+    allp = pts + bad
+    arr = np.frombuffer(b"".join(M.i2b(C, x) + M.i2b(C, y) for x, y in allp), dtype=np.uint8).reshape(-1, 64).copy()
+    assert list(curve.validate_points(arr)) == [1] * 20 + [0] * 7 + [1]
+    xs = [p[0] for p in pts] + [rng.randrange(P) for _ in range(40)] + [P, P + 1]
+    odd = [p[1] & 1 for p in pts] + [rng.randrange(2) for _ in range(42)]
+    out, okd = curve.decompress(fe_bytes(xs), np.array(odd, dtype=np.uint8))
+    for i, (x, o) in enumerate(zip(xs, odd)):
+        want = M.decompress(C, x, o)
+        if want is None:
+            assert okd[i] == 0 and not out[i].any()
+        else:
+            assert okd[i] == 1 and bytes(out[i]) == M.i2b(C, want[0]) + M.i2b(C, want[1])
+
+
+def test_synth_streams_match_spec_and_device_pointers(curve):
+    """Device generators reproduce oracle/synth.py; the ABI accepts device pointers (torch tensors)."""
+    import torch
+    n = 512
+    first = 12345
+    d_s = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    d_p = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    d_o = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    curve.synth_scalars_device(d_s, n, synth.SEED, first)
+    curve.synth_points_device(d_p, n, synth.SEED, first)
+    curve.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i)
+    curve.ctx.synchronize()
+    s, p, o = d_s.cpu().numpy(), d_p.cpu().numpy(), d_o.cpu().numpy()
+    for i in range(0, n, 7):
+        k = synth.scalar(C, first + i)
+        pt = synth.point(C, first + i)
+        assert bytes(s[i]) == M.i2b(C, k)
+        assert bytes(p[i]) == M.i2b(C, pt[0]) + M.i2b(C, pt[1])
+        w = M.affine_mul(C, k, pt)
+        assert bytes(o[i]) == M.i2b(C, w[0]) + M.i2b(C, w[1])
+    assert not d_i.cpu().numpy().any()
