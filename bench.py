@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): k256 variable-base scalar multiplications per second.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE).  A "step" is one pass
+of the hot path over one batch: 2^24 independent (scalar, point) pairs per GPU (BASELINE.json
+configs[1]), inputs generated on the device from the synthetic-input spec (oracle/synth.py) and
+resident in HBM before the timed region.  Independent batches shard across GPUs with no
+data-path collective (weak scaling: per-GPU work is fixed); the only communication is the
+barrier and the max-over-ranks of the elapsed time.
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
+  roofline     the dominant kernel against its bound.  This path is integer-VALU bound (no MFMA,
+               ~0.2 % of HBM): `bound` is "valu", achieved/peak are 32x32-bit multiply-accumulates
+               per second (v_mad_u64_u32 issue rate); the HBM view of the same kernel is under
+               roofline["hbm"] (algorithmic bytes, GB/s, fraction of 8 TB/s, PMC traffic if a
+               profiles/ summary is present).
+  cpu_baseline the C restatement of the reference CPU path (oracle/ecoracle.c, "port": rustc is not
+               available) timed on this box's host cores on a bounded sample of the same workload,
+               and used to check the GPU output of that sample byte for byte.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "rustcrypto-elliptic-curves_amd"))
+
+SEED = 0xEC5CA1A5
+
+# ---- algorithmic work per unit (DESIGN.md section "Kernels and rooflines") ---------------------
+# unit = one k256 variable-base scalar multiplication with affine output.
+# 32x32-bit multiply-accumulates of the schoolbook products, 64 per 256-bit modular multiplication
+# or squaring; reduction and additions are not counted.
+MODMUL_PER_UNIT = {
+    # reference schedule: 128 doublings (6M+2S) + 80 additions (12M) + to_affine (255S + 17M)
+    "k256_varbase_ref": 128 * 8 + 80 * 12 + 272,
+}
+MAC_PER_MODMUL = 64
+BYTES_PER_UNIT = 32 + 64 + 65          # scalar + affine point in, x||y||inf out
+# v_mad_u64_u32 issues at half the FP32-FMA rate on gfx950 (measured, tools/ubench/valu_rates.hip):
+# 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz
+PEAK_TMACS = 256 * 4 * 16 * 2.4e9 / 1e12
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline_worker(args):
+    """Runs in a forked child BEFORE the parent touches the GPU: C oracle on a slice."""
+    first, n = args
+    from oracle import coracle as CO
+    s = CO.synth_scalars(0, n, SEED, first)
+    p = CO.synth_points(0, n, SEED, first)
+    t0 = time.perf_counter()
+    out = CO.lincomb_batch(0, s, p, threads=1)
+    dt = time.perf_counter() - t0
+    return first, n, dt, out.tobytes()
+
+
+def run_cpu_baseline(sample, procs):
+    """Reference CPU path (C port) on `sample` units spread over `procs` single-threaded processes."""
+    from concurrent.futures import ProcessPoolExecutor
+    per = (sample + procs - 1) // procs
+    jobs = [(i * per, min(per, sample - i * per)) for i in range(procs) if i * per < sample]
+    t0 = time.perf_counter()
+    with ProcessPoolExecutor(max_workers=procs) as ex:
+        res = list(ex.map(cpu_baseline_worker, jobs))
+    wall = time.perf_counter() - t0
+    busy = max(r[2] for r in res)      # slowest worker, excludes process start-up and input synthesis
+    outs = b"".join(r[3] for r in sorted(res))
+    return {"wall_s": wall, "busy_s": busy, "out": outs, "procs": len(jobs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log2n", type=int, default=24, help="units per GPU per step (BASELINE config: 2^24)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="units for the CPU baseline (0 = auto, about 10-20 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n = 1 << args.log2n
+
+    # ---- CPU baseline first (rank 0, N = 1 only), before this process initialises the GPU ----------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        procs = max(1, min(os.cpu_count() or 1, 16))
+        # the C port runs ~16 k units/s/core: 64 k units per process is ~4 s of work each (about a minute of CPU
+        # time on 16 cores); --cpu-sample overrides
+        sample = args.cpu_sample or min(n, 65536 * procs)
+        cpu = run_cpu_baseline(sample, procs)
+        cpu["sample"] = sample
+
+    import numpy as np
+    import torch
+    import ecgpu
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    ctx = ecgpu.Context(local_rank)
+    cv = ctx.curve("k256")
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    dev = torch.device("cuda", local_rank)
+    d_s = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    d_p = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    d_o = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    d_i = torch.empty((n,), dtype=torch.uint8, device=dev)
+    first = rank * n                         # disjoint slices of one global batch
+    cv.synth_scalars_device(d_s, n, SEED, first)
+    cv.synth_points_device(d_p, n, SEED, first)
+    torch.cuda.synchronize()
+
+    def step():
+        cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()                        # HIP events on the launch stream bracket the same region
+    for _ in range(args.steps):
+        step()
+    kernel_ms = ctx.timer_stop()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- parity of the sample against the CPU oracle (same seeded inputs) ----------------------------
+    parity = None
+    if cpu is not None:
+        m = cpu["sample"]
+        got = torch.cat([d_o[:m], d_i[:m, None]], dim=1).cpu().numpy().tobytes()
+        parity = (got == cpu["out"])
+        if not parity:
+            raise SystemExit("PARITY FAILURE: GPU output differs from the CPU oracle on the sampled units")
+
+    if rank == 0:
+        units = world * n * args.steps
+        value = units / elapsed
+        kernel_s = kernel_ms / 1e3 / args.steps            # average launch duration, HIP events
+        modmul = MODMUL_PER_UNIT["k256_varbase_ref"]
+        macs_per_launch = n * modmul * MAC_PER_MODMUL
+        achieved_tmacs = macs_per_launch / kernel_s / 1e12
+        alg_bytes = n * BYTES_PER_UNIT
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "k256 variable-base scalar-muls/sec",
+            "value": value,
+            "unit": "scalar-muls/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "k256 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output" % args.log2n,
+                       "units_per_gpu_per_step": n, "parallelism": "independent batches, %d GPU(s), no collective" % world,
+                       "schedule": "reference (GLV + signed radix-16, RCB complete formulas)"},
+            "roofline": {
+                "bound": "valu", "achieved": achieved_tmacs, "peak": PEAK_TMACS, "unit": "TMAC/s (32x32+64 v_mad_u64_u32)",
+                "frac": achieved_tmacs / PEAK_TMACS, "traffic": traffic,
+                "kernel": "lincomb_ref_kernel<CurveK256,1>", "kernel_ms": kernel_s * 1e3,
+                "modmul_per_unit": modmul, "mac_per_unit": modmul * MAC_PER_MODMUL,
+                "hbm": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": alg_bytes / kernel_s / 1e9 / PEAK_HBM_GBS, "bytes_per_unit": BYTES_PER_UNIT},
+            },
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = {
+                "value": cpu["sample"] / cpu["busy_s"], "unit": "scalar-muls/s", "cores": cpu["procs"], "kind": "port",
+                "sample": "first %d units of the same seeded batch, C restatement of the reference path (oracle/ecoracle.c), %d single-threaded processes; GPU output of the sample verified byte-identical" % (cpu["sample"], cpu["procs"]),
+                "wall_s": cpu["wall_s"], "parity_ok": bool(parity),
+            }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

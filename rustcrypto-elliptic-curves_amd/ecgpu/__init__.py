@@ -18,6 +18,11 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+try:  # one HIP runtime per process: let torch's bundled libamdhip64 load first so that libecgpu.so
+    import torch  # noqa: F401  binds to the same copy (device pointers / streams are then shared)
+except ImportError:  # torch is optional plumbing; the C ABI itself needs only the ROCm runtime
+    torch = None
+
 HOST, DEVICE = 0, 1
 AFFINE, PROJECTIVE = 0, 1
 EXACT_REFERENCE = 1
