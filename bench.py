@@ -39,6 +39,11 @@ SEED = 0xEC5CA1A5
 MODMUL_PER_UNIT = {
     # reference schedule: 128 doublings (6M+2S) + 80 additions (12M) + to_affine (255S + 17M)
     "k256_varbase_ref": 128 * 8 + 80 * 12 + 272,
+    # throughput schedule (csrc/mulfast_k256.hpp): Jacobian, common-Z table, batched inversion (batch 16)
+    #   table   : 1 dbl (3M+4S) + 6 mixed adds (8M+3S) + rescale 7M + 7x(3M+1S) + 8 beta*x  =  87M + 29S
+    #   loop    : 128 dbl (3M+4S) + 66 mixed adds (8M+3S)                                   = 912M + 710S
+    #   output  : 2M (global Z) + batched normalise 6M+1S + (255S+15M)/16                   =   9M +  17S
+    "k256_varbase_fast": (87 + 912 + 9) + (29 + 710 + 17),
 }
 MAC_PER_MODMUL = 64
 BYTES_PER_UNIT = 32 + 64 + 65          # scalar + affine point in, x||y||inf out
@@ -82,6 +87,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=24, help="units per GPU per step (BASELINE config: 2^24)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="units for the CPU baseline (0 = auto, about 10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--schedule", choices=["fast", "ref"], default="fast",
+                    help="fast = throughput schedule (affine result specified); ref = reference-faithful schedule (exact XYZ)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,7 +136,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i)
+        cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i, flags=(ecgpu.EXACT_REFERENCE if args.schedule == "ref" else 0))
 
     def barrier():
         if dist is not None:
@@ -164,7 +171,7 @@ def main():
         units = world * n * args.steps
         value = units / elapsed
         kernel_s = kernel_ms / 1e3 / args.steps            # average launch duration, HIP events
-        modmul = MODMUL_PER_UNIT["k256_varbase_ref"]
+        modmul = MODMUL_PER_UNIT["k256_varbase_" + args.schedule]
         macs_per_launch = n * modmul * MAC_PER_MODMUL
         achieved_tmacs = macs_per_launch / kernel_s / 1e12
         alg_bytes = n * BYTES_PER_UNIT
@@ -191,11 +198,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": "k256 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output" % args.log2n,
                        "units_per_gpu_per_step": n, "parallelism": "independent batches, %d GPU(s), no collective" % world,
-                       "schedule": "reference (GLV + signed radix-16, RCB complete formulas)"},
+                       "schedule": ("reference-faithful (GLV + signed radix-16, RCB complete formulas, per-point inversion)" if args.schedule == "ref"
+                                    else "throughput (GLV + signed radix-16, Jacobian, common-Z table, batched inversion)")},
             "roofline": {
                 "bound": "valu", "achieved": achieved_tmacs, "peak": PEAK_TMACS, "unit": "TMAC/s (32x32+64 v_mad_u64_u32)",
                 "frac": achieved_tmacs / PEAK_TMACS, "traffic": traffic,
-                "kernel": "lincomb_ref_kernel<CurveK256,1>", "kernel_ms": kernel_s * 1e3,
+                "kernel": ("lincomb_ref_kernel<CurveK256,1>" if args.schedule == "ref" else "k256_mul_fast_kernel<16>"), "kernel_ms": kernel_s * 1e3,
                 "modmul_per_unit": modmul, "mac_per_unit": modmul * MAC_PER_MODMUL,
                 "hbm": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": alg_bytes / kernel_s / 1e9 / PEAK_HBM_GBS, "bytes_per_unit": BYTES_PER_UNIT},

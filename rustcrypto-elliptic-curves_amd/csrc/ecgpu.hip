@@ -162,7 +162,6 @@ static int ensure_gen_table(ecgpu_ctx* c) {
 template <class C>
 static int lincomb_launch(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt,
                           uint8_t* out_inf, size_t n, unsigned flags) {
-  (void)flags;
   const unsigned g = grid_for(c, n, 4);
   if (!pts) {
     if (terms != 1) return set_err(c, ECGPU_ERR_ARG, "generator multiplication takes one term");
@@ -170,6 +169,10 @@ static int lincomb_launch(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fm
     if (rc) return rc;
     hipLaunchKernelGGL((mul_gen_ref_kernel<C>), dim3(g), dim3(256), 0, c->stream, sc, (const typename C::Pt*)c->gen_table[C::ID],
                        out, out_fmt, out_inf, n);
+  } else if (terms == 1 && C::ID == 0 && !(flags & ECGPU_EXACT_REFERENCE)) {
+    // throughput schedule: grid sized so that every lane owns a batch worth of elements when n allows
+    hipLaunchKernelGGL((k256_mul_fast_kernel<16>), dim3(grid_for(c, n, 2)), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt,
+                       out_inf, n);
   } else if (terms == 1) {
     hipLaunchKernelGGL((lincomb_ref_kernel<C, 1>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
   } else if (terms == 2) {

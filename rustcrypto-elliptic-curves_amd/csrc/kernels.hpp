@@ -7,6 +7,7 @@
 // DESIGN.md); what matters is VGPR pressure and instruction count.
 #pragma once
 #include "traits.hpp"
+#include "mulfast_k256.hpp"
 
 namespace ecgpu {
 
@@ -136,6 +137,103 @@ __global__ void __launch_bounds__(256) lincomb_ref_kernel(const u32* scalars, co
     C::template lincomb_ref<NT>(r, pts, ks, tab);
     if (out_fmt == FMT_PROJECTIVE) store_projective<C>(out + i * 3 * C::NW, r);
     else store_affine_from_projective<C>(out + i * 2 * C::NW, out_inf ? out_inf + i : nullptr, r);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// k256 variable-base scalar multiplication, throughput schedule (mulfast_k256.hpp).
+// Each lane walks its elements with a grid stride, keeps up to BATCH Jacobian results in its
+// private segment and converts them to affine with one shared inversion.
+// ---------------------------------------------------------------------------------------------
+template <int BATCH>
+__global__ void __launch_bounds__(256) k256_mul_fast_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out,
+                                                            int out_fmt, uint8_t* out_inf, size_t n) {
+  TabEntryK256 tab[8];
+  JacK256 res[BATCH];
+  FeK256 pre[BATCH];
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int pw = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * 8;
+  for (size_t base = tid; base < n; base += T * BATCH) {
+    int cnt = 0;
+#pragma unroll 1
+    for (int j = 0; j < BATCH; j++) {
+      const size_t i = base + (size_t)j * T;
+      if (i >= n) break;
+      u32 k[8];
+      words_load_be<8>(k, scalars + i * 8);
+      k256::scalar_reduce_once(k);
+      FeK256 px, py, pz;
+      bool p_inf;
+      const u32* src = points + i * pw;
+      k256::from_be_words(px, src);
+      k256::from_be_words(py, src + 8);
+      if (pt_fmt == FMT_PROJECTIVE) {
+        // homogeneous (X:Y:Z) = Jacobian (XZ, YZ^2, Z): run on the curve isomorphic by u = Z
+        k256::from_be_words(pz, src + 16);
+        p_inf = k256::is_zero(pz);
+        FeK256 zz;
+        k256::mul(px, px, pz);
+        k256::sqr(zz, pz);
+        k256::mul(py, py, zz);
+      } else {
+        u32 z = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) z |= src[w];
+        p_inf = (z == 0);
+        k256::set_one(pz);
+      }
+      if (p_inf) {   // keep the arithmetic on a valid point; the result is replaced below
+        PtK256 g; k256::generator(g);
+        px = g.x; py = g.y; k256::set_one(pz);
+      }
+      k256::mul_fast_jac(res[j], px, py, k, tab);
+      k256::mul(res[j].z, res[j].z, pz);
+      FeK256 zero; k256::set_zero(zero);
+      k256::select(res[j].z, p_inf, zero, res[j].z);
+      cnt = j + 1;
+    }
+    // batched conversion; write results as they are produced
+    {
+      FeK256 acc; k256::set_one(acc);
+#pragma unroll 1
+      for (int j = 0; j < cnt; j++) {
+        pre[j] = acc;
+        FeK256 z = res[j].z, one; k256::set_one(one);
+        k256::select(z, k256::is_zero(z), one, z);
+        k256::mul(acc, acc, z);
+      }
+      FeK256 ai;
+      k256::inv(ai, acc);
+#pragma unroll 1
+      for (int j = cnt - 1; j >= 0; j--) {
+        const size_t i = base + (size_t)j * T;
+        FeK256 z = res[j].z, one, zero; k256::set_one(one); k256::set_zero(zero);
+        const bool zr = k256::is_zero(z);
+        k256::select(z, zr, one, z);
+        FeK256 zi, zi2, zi3, x, y;
+        k256::mul(zi, ai, pre[j]);
+        k256::mul(ai, ai, z);
+        k256::sqr(zi2, zi);
+        k256::mul(zi3, zi2, zi);
+        k256::mul(x, res[j].x, zi2);
+        k256::mul(y, res[j].y, zi3);
+        k256::select(x, zr, zero, x);
+        if (out_fmt == FMT_PROJECTIVE) {
+          // (x : y : 1), identity (0 : 1 : 0)
+          k256::select(y, zr, one, y);
+          u32* o = out + i * 24;
+          CurveK256::fe_store(o, x); CurveK256::fe_store(o + 8, y);
+          CurveK256::fe_store(o + 16, zr ? zero : one);
+        } else {
+          k256::select(y, zr, zero, y);
+          u32* o = out + i * 16;
+          CurveK256::fe_store(o, x); CurveK256::fe_store(o + 8, y);
+          if (out_inf) out_inf[i] = zr ? 1 : 0;
+        }
+      }
+    }
   }
 }
 

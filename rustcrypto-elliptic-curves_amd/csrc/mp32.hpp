@@ -20,7 +20,7 @@
 #include <hip/hip_runtime.h>
 #define ECGPU_HD __host__ __device__ __forceinline__
 #else
-#define ECGPU_HD inline __attribute__((always_inline))
+#define ECGPU_HD inline
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -1,0 +1,199 @@
+// secp256k1 variable-base scalar multiplication, throughput schedule.
+//
+// Contract: the group element k*P (affine bytes), not the reference's projective triple - so the
+// schedule is free.  Same outer structure as k256/src/arithmetic/mul.rs
+// (GLV split, signed radix-16 digits, 4 doublings + 2 table additions per digit) but
+//   * Jacobian coordinates: doubling 3M+4S and mixed addition 8M+3S instead of the complete
+//     homogeneous formulas (8 and 12 multiplications); the exceptional cases of the incomplete
+//     formulas are detected and handled explicitly so every input gives the right answer;
+//   * one table [P..8P] brought to a common Z ("effective affine": the whole multiplication runs
+//     on the isomorphic curve y^2 = x^3 + 7 Z8^6, the final Z is multiplied by Z8), with beta*x kept
+//     beside x so the lambda-half of the GLV split reads the same table;
+//   * the conversion to affine is batched per lane over consecutive results (Montgomery's trick,
+//     BatchInvert / batch_normalize, k256 projective.rs:325-379): one field inversion per BATCH
+//     points instead of one per point.
+// This path is not constant-time (the reference's is); it is meant for bulk public data.
+#pragma once
+#include "curve_k256.hpp"
+
+namespace ecgpu {
+
+struct JacK256 {   // x = X / Z^2, y = Y / Z^3, infinity <=> Z == 0
+  FeK256 x, y, z;
+};
+struct TabEntryK256 {   // affine point on the isomorphic curve, with beta*x alongside
+  FeK256 x, bx, y;
+};
+
+namespace k256 {
+
+// dbl, a = 0: A = X^2, B = Y^2, C = B^2, D = 4 X B, E = 3 A, X3 = E^2 - 2D, Y3 = E (D - X3) - 8C, Z3 = 2 Y Z
+ECGPU_HD void jac_double(JacK256& r, const JacK256& p) {
+  FeK256 a, b, c, d, e, t;
+  sqr(a, p.x);
+  sqr(b, p.y);
+  sqr(c, b);
+  mul(d, p.x, b); dbl(d, d); dbl(d, d);
+  dbl(e, a); add(e, e, a);
+  mul(t, p.y, p.z); dbl(r.z, t);
+  sqr(t, e);
+  FeK256 d2; dbl(d2, d);
+  sub(r.x, t, d2);
+  sub(t, d, r.x); mul(t, e, t);
+  dbl(c, c); dbl(c, c); dbl(c, c);
+  sub(r.y, t, c);
+}
+
+// doubling of an affine point (Z = 1)
+ECGPU_HD void jac_double_affine(JacK256& r, const FeK256& x, const FeK256& y) {
+  JacK256 p;
+  p.x = x; p.y = y; set_one(p.z);
+  jac_double(r, p);
+}
+
+// r = p + (x2, y2) for an affine, non-identity (x2, y2).  8M + 3S.  `zr` (optional) receives the
+// ratio Z3 / Z1 = H, which the table construction needs.
+//   P at infinity            -> (x2, y2, 1)
+//   same x, same y (H=R=0)   -> doubling of (x2, y2)
+//   same x, opposite y       -> Z3 = Z1 * 0 = 0: infinity falls out of the formula
+ECGPU_HD void jac_add_mixed(JacK256& r, const JacK256& p, const FeK256& x2, const FeK256& y2, FeK256* zr) {
+  FeK256 z1z1, u2, s2, h, rr, hh, hhh, v, t;
+  sqr(z1z1, p.z);
+  mul(u2, x2, z1z1);
+  mul(s2, p.z, z1z1); mul(s2, s2, y2);
+  sub(h, u2, p.x);
+  sub(rr, s2, p.y);
+  const bool p_inf = is_zero(p.z);
+  const bool same = is_zero(h) && is_zero(rr) && !p_inf;
+  sqr(hh, h);
+  mul(hhh, hh, h);
+  mul(v, p.x, hh);
+  JacK256 o;
+  sqr(t, rr);
+  sub(t, t, hhh);
+  FeK256 v2; dbl(v2, v);
+  sub(o.x, t, v2);
+  sub(t, v, o.x); mul(t, rr, t);
+  FeK256 yh; mul(yh, p.y, hhh);
+  sub(o.y, t, yh);
+  mul(o.z, p.z, h);
+  if (zr) *zr = h;
+  if (__builtin_expect(same, 0)) {   // never taken for honest GLV digits; kept exact
+    JacK256 d;
+    jac_double_affine(d, x2, y2);
+    select(o.x, same, d.x, o.x); select(o.y, same, d.y, o.y); select(o.z, same, d.z, o.z);
+    if (zr) { FeK256 y2d; dbl(y2d, y2); select(*zr, same, y2d, *zr); }   // not used on that path
+  }
+  FeK256 one; set_one(one);
+  select(r.x, p_inf, x2, o.x);
+  select(r.y, p_inf, y2, o.y);
+  select(r.z, p_inf, one, o.z);
+}
+
+// [P, 2P, .., 8P] with a common denominator.  On return tab[j-1] = (x', beta x', y') are the affine
+// coordinates of jP on the curve isomorphic by u = `zglobal` (x' = x u^2, y' = y u^3), i.e. Jacobian
+// coordinates (x', y', zglobal) of jP on secp256k1.  P must not be the identity.
+ECGPU_HD void table_build_globalz(TabEntryK256* tab, FeK256& zglobal, const FeK256& px, const FeK256& py) {
+  JacK256 m[8];       // m[j] = (j+1) P, Jacobian
+  FeK256 zr[8];       // zr[j] = Z(m[j]) / Z(m[j-1]),  j >= 2
+  m[0].x = px; m[0].y = py; set_one(m[0].z);
+  jac_double_affine(m[1], px, py);
+#pragma unroll 1
+  for (int j = 2; j < 8; j++) jac_add_mixed(m[j], m[j - 1], px, py, &zr[j]);
+  zglobal = m[7].z;
+  FeK256 beta_; beta(beta_);
+  // scale m[j] to the denominator of m[7]: s_j = Z7 / Z_j = prod_{i > j} zr[i]
+  FeK256 s; set_one(s);
+  tab[7].x = m[7].x; tab[7].y = m[7].y;
+  mul(tab[7].bx, tab[7].x, beta_);
+#pragma unroll 1
+  for (int j = 6; j >= 0; j--) {
+    if (j >= 1) mul(s, s, zr[j + 1]);        // s = Z7 / Z_j for j >= 1 (Z_1 = Z(m[1]))
+    else mul(s, s, m[1].z);                  // j = 0: Z_0 = 1, so s = Z7
+    FeK256 s2, s3;
+    sqr(s2, s);
+    mul(s3, s2, s);
+    mul(tab[j].x, m[j].x, s2);
+    mul(tab[j].y, m[j].y, s3);
+    mul(tab[j].bx, tab[j].x, beta_);
+  }
+}
+
+// Adds digit d of one GLV half: d in [-8, 8], `lam` selects beta*x, `neg` is the sign of that half.
+ECGPU_HD void add_digit(JacK256& acc, const TabEntryK256* tab, int d, bool lam, bool neg) {
+  const int ad = d < 0 ? -d : d;
+  const TabEntryK256& e = tab[ad ? ad - 1 : 0];
+  FeK256 x, y, ny;
+  select(x, lam, e.bx, e.x);
+  neg ^= (d < 0);
+  k256::neg(ny, e.y);
+  select(y, neg, ny, e.y);
+  JacK256 s;
+  jac_add_mixed(s, acc, x, y, nullptr);
+  const bool skip = (ad == 0);
+  select(acc.x, skip, acc.x, s.x); select(acc.y, skip, acc.y, s.y); select(acc.z, skip, acc.z, s.z);
+}
+
+// k * P for an affine, non-identity P; result in Jacobian coordinates on secp256k1.
+ECGPU_HD void mul_fast_jac(JacK256& acc, const FeK256& px, const FeK256& py, const u32* k, TabEntryK256* tab) {
+  GlvSplit s;
+  glv_split(s, k);
+  FeK256 zg;
+  table_build_globalz(tab, zg, px, py);
+  Radix16<4> d1, d2;
+  radix16_recode<4>(d1, s.k1);
+  radix16_recode<4>(d2, s.k2);
+  set_zero(acc.x); set_zero(acc.y); set_zero(acc.z);      // infinity
+  add_digit(acc, tab, (int)d1.top, false, s.neg1);
+  add_digit(acc, tab, (int)d2.top, true, s.neg2);
+#pragma unroll 1
+  for (int i = 31; i >= 0; i--) {
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) jac_double(acc, acc);
+    u32 w1 = d1.y[0], w2 = d2.y[0];
+#pragma unroll
+    for (int q = 1; q < 4; q++) { w1 = (i >> 3) == q ? d1.y[q] : w1; w2 = (i >> 3) == q ? d2.y[q] : w2; }
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) add_digit(acc, tab, radix16_digit(h ? w2 : w1, i & 7), h != 0, h ? s.neg2 : s.neg1);
+  }
+  mul(acc.z, acc.z, zg);     // back from the isomorphic curve
+}
+
+// Montgomery's trick over `cnt` Jacobian points held by this lane: one inversion for all of them.
+// zs is scratch for cnt prefix products.  Writes canonical affine x, y limbs (0, 0 for infinity).
+template <int MAXB>
+ECGPU_HD void jac_batch_to_affine(FeK256* ax, FeK256* ay, u32* inf, const JacK256* pts, int cnt, FeK256* pre) {
+  FeK256 acc; set_one(acc);
+#pragma unroll 1
+  for (int i = 0; i < cnt; i++) {
+    pre[i] = acc;                                     // product of the non-zero Z before i
+    FeK256 z = pts[i].z;
+    const bool zr = is_zero(z);
+    FeK256 one; set_one(one);
+    select(z, zr, one, z);
+    mul(acc, acc, z);
+  }
+  FeK256 ai;
+  inv(ai, acc);
+#pragma unroll 1
+  for (int i = cnt - 1; i >= 0; i--) {
+    FeK256 z = pts[i].z;
+    const bool zr = is_zero(z);
+    FeK256 one; set_one(one);
+    select(z, zr, one, z);
+    FeK256 zi, zi2, zi3;
+    mul(zi, ai, pre[i]);                              // 1 / z_i
+    mul(ai, ai, z);                                   // inverse of the product before i
+    sqr(zi2, zi);
+    mul(zi3, zi2, zi);
+    FeK256 x, y, zero; set_zero(zero);
+    mul(x, pts[i].x, zi2);
+    mul(y, pts[i].y, zi3);
+    select(ax[i], zr, zero, x);
+    select(ay[i], zr, zero, y);
+    inf[i] = zr ? 1u : 0u;
+  }
+}
+
+}  // namespace k256
+}  // namespace ecgpu

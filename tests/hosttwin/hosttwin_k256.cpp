@@ -80,3 +80,63 @@ int ht_k256_to_affine(const uint8_t* pts, uint8_t* out, int n) {
   return 0;
 }
 }
+
+// ---- throughput schedule (mulfast_k256.hpp) -----------------------------------------------------
+#include "mulfast_k256.hpp"
+extern "C" {
+// points: affine x||y (zeros = identity) or, with proj != 0, homogeneous X||Y||Z; out: x||y||inf (65 B)
+int ht_k256_mul_fast(const uint8_t* pts, int proj, const uint8_t* ks, uint8_t* out, int n, int batch) {
+  TabEntryK256 tab[8];
+  JacK256* res = (JacK256*)malloc(sizeof(JacK256) * batch);
+  FeK256* pre = (FeK256*)malloc(sizeof(FeK256) * batch * 3);
+  u32* inf = (u32*)malloc(sizeof(u32) * batch);
+  const int pw = proj ? 96 : 64;
+  for (int base = 0; base < n; base += batch) {
+    int cnt = (n - base < batch) ? n - base : batch;
+    for (int j = 0; j < cnt; j++) {
+      const uint8_t* src = pts + (size_t)pw * (base + j);
+      FeK256 px, py, pz; load(px, src); load(py, src + 32);
+      bool p_inf;
+      if (proj) {
+        load(pz, src + 64); p_inf = k256::is_zero(pz);
+        FeK256 zz; k256::mul(px, px, pz); k256::sqr(zz, pz); k256::mul(py, py, zz);
+      } else {
+        int z = 1; for (int b = 0; b < 64; b++) z &= (src[b] == 0);
+        p_inf = z; k256::set_one(pz);
+      }
+      if (p_inf) { PtK256 g; k256::generator(g); px = g.x; py = g.y; k256::set_one(pz); }
+      u32 k[8]; load_scalar(k, ks + 32 * (base + j));
+      k256::scalar_reduce_once(k);
+      k256::mul_fast_jac(res[j], px, py, k, tab);
+      k256::mul(res[j].z, res[j].z, pz);
+      FeK256 zero; k256::set_zero(zero);
+      k256::select(res[j].z, p_inf, zero, res[j].z);
+    }
+    k256::jac_batch_to_affine<0>(pre + batch, pre + 2 * batch, inf, res, cnt, pre);
+    for (int j = 0; j < cnt; j++) {
+      uint8_t* o = out + 65 * (size_t)(base + j);
+      store(o, pre[batch + j]); store(o + 32, pre[2 * batch + j]); o[64] = (uint8_t)inf[j];
+    }
+  }
+  free(res); free(pre); free(inf);
+  return 0;
+}
+// r = P + Q with P Jacobian (X||Y||Z, x = X/Z^2) and Q affine: out Jacobian X||Y||Z (canonical bytes)
+int ht_k256_jac_add_mixed(const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
+  for (int i = 0; i < n; i++) {
+    JacK256 a, r; load(a.x, p + 96 * i); load(a.y, p + 96 * i + 32); load(a.z, p + 96 * i + 64);
+    FeK256 x, y; load(x, q + 64 * i); load(y, q + 64 * i + 32);
+    k256::jac_add_mixed(r, a, x, y, nullptr);
+    store(out + 96 * i, r.x); store(out + 96 * i + 32, r.y); store(out + 96 * i + 64, r.z);
+  }
+  return 0;
+}
+int ht_k256_jac_double(const uint8_t* p, uint8_t* out, int n) {
+  for (int i = 0; i < n; i++) {
+    JacK256 a, r; load(a.x, p + 96 * i); load(a.y, p + 96 * i + 32); load(a.z, p + 96 * i + 64);
+    k256::jac_double(r, a);
+    store(out + 96 * i, r.x); store(out + 96 * i + 32, r.y); store(out + 96 * i + 64, r.z);
+  }
+  return 0;
+}
+}

@@ -13,7 +13,7 @@ d_p = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
 d_o = torch.empty((n, 96), dtype=torch.uint8, device="cuda")
 d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
 cv.synth_scalars_device(d_s, n, synth.SEED); cv.synth_points_device(d_p, n, synth.SEED); ctx.synchronize()
-for name, flags, fmt in (("mul exact-ref proj-out", ecgpu.EXACT_REFERENCE, ecgpu.PROJECTIVE), ("mul default affine-out", 0, ecgpu.AFFINE)):
+for name, flags, fmt in (("mul exact-ref affine-out", ecgpu.EXACT_REFERENCE, ecgpu.AFFINE), ("mul fast affine-out", 0, ecgpu.AFFINE)):
     for rep in range(3):
         ctx.timer_start()
         cv.mul_device(d_s, d_p, d_o, n, out_format=fmt, d_out_inf=d_i, flags=flags)
