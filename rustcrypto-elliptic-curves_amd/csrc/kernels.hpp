@@ -145,11 +145,135 @@ __global__ void __launch_bounds__(256) lincomb_ref_kernel(const u32* scalars, co
 // k256 variable-base scalar multiplication, throughput schedule (mulfast_k256.hpp).
 // Each lane walks its elements with a grid stride, keeps up to BATCH Jacobian results in its
 // private segment and converts them to affine with one shared inversion.
+//
+// WAVES is the occupancy target handed to the register allocator through __launch_bounds__: left
+// alone it spends 256 VGPRs (+AGPRs) on instruction-level parallelism and ends at one wave per SIMD;
+// with WAVES = 3 it fits 168 VGPRs with two spilled dwords, with WAVES = 4 128 VGPRs and 38 spilled
+// dwords (callable device functions cannot carry an occupancy target, so the phases are inlined).
 // ---------------------------------------------------------------------------------------------
-template <int BATCH>
-__global__ void __launch_bounds__(256) k256_mul_fast_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out,
+struct K256FastPrep {
+  u32 y1[4], y2[4];     // recoded magnitudes of the two GLV halves (radix16_recode)
+  u32 top1, top2;       // 33rd digits
+  u32 neg1, neg2;       // signs of the halves
+  u32 p_inf;
+  FeK256 zfix;          // common table denominator times the input's own Z
+};
+
+__device__ __forceinline__ void k256_fast_prep(K256FastPrep* pp, TabEntryK256* tab, const u32* sc, const u32* src, int pt_fmt) {
+  u32 k[8];
+  words_load_be<8>(k, sc);
+  k256::scalar_reduce_once(k);
+  k256::GlvSplit s;
+  k256::glv_split(s, k);
+  k256::Radix16<4> d1, d2;
+  k256::radix16_recode<4>(d1, s.k1);
+  k256::radix16_recode<4>(d2, s.k2);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { pp->y1[i] = d1.y[i]; pp->y2[i] = d2.y[i]; }
+  pp->top1 = d1.top; pp->top2 = d2.top;
+  pp->neg1 = s.neg1; pp->neg2 = s.neg2;
+
+  FeK256 px, py, pz;
+  bool p_inf;
+  k256::from_be_words(px, src);
+  k256::from_be_words(py, src + 8);
+  if (pt_fmt == FMT_PROJECTIVE) {
+    // homogeneous (X:Y:Z) = Jacobian (XZ, YZ^2, Z): run on the curve isomorphic by u = Z
+    k256::from_be_words(pz, src + 16);
+    p_inf = k256::is_zero(pz);
+    FeK256 zz;
+    k256::mul(px, px, pz);
+    k256::sqr(zz, pz);
+    k256::mul(py, py, zz);
+  } else {
+    u32 z = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) z |= src[w];
+    p_inf = (z == 0);
+    k256::set_one(pz);
+  }
+  if (p_inf) {   // keep the arithmetic on a valid point; the result is replaced by the identity
+    PtK256 g; k256::generator(g);
+    px = g.x; py = g.y; k256::set_one(pz);
+  }
+  pp->p_inf = p_inf ? 1u : 0u;
+  FeK256 zg;
+  k256::table_build_globalz(tab, zg, px, py);
+  k256::mul(pp->zfix, zg, pz);
+}
+
+__device__ __forceinline__ void k256_fast_loop(JacK256* out, const K256FastPrep* pp, const TabEntryK256* tab) {
+  u32 y1[4], y2[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { y1[i] = pp->y1[i]; y2[i] = pp->y2[i]; }
+  const bool n1 = pp->neg1 != 0, n2 = pp->neg2 != 0;
+  JacK256 acc;
+  k256::set_zero(acc.x); k256::set_zero(acc.y); k256::set_zero(acc.z);      // infinity
+  // digit 32 (the carry digits) then digits 31..0; one shared body for all 33 positions
+#pragma unroll 1
+  for (int i = 32; i >= 0; i--) {
+    if (i != 32) {
+#pragma unroll 1
+      for (int j = 0; j < 4; j++) k256::jac_double(acc);
+    }
+    u32 w1 = y1[0], w2 = y2[0];
+#pragma unroll
+    for (int q = 1; q < 4; q++) { w1 = (i >> 3) == q ? y1[q] : w1; w2 = (i >> 3) == q ? y2[q] : w2; }
+    int dg1 = k256::radix16_digit(w1, i & 7), dg2 = k256::radix16_digit(w2, i & 7);
+    if (i == 32) { dg1 = (int)pp->top1; dg2 = (int)pp->top2; }
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) k256::add_digit(acc, tab, h ? dg2 : dg1, h != 0, h ? n2 : n1);
+  }
+  k256::mul(acc.z, acc.z, pp->zfix);     // back from the isomorphic curves
+  if (pp->p_inf) k256::set_zero(acc.z);
+  *out = acc;
+}
+
+// Montgomery's trick over the cnt results of this lane; element j of the batch is global index base + j*T.
+__device__ __forceinline__ void k256_fast_finish(const JacK256* res, FeK256* pre, int cnt, size_t base, size_t T, u32* out, int out_fmt,
+                                              uint8_t* out_inf) {
+  FeK256 acc; k256::set_one(acc);
+#pragma unroll 1
+  for (int j = 0; j < cnt; j++) {
+    pre[j] = acc;
+    FeK256 z = res[j].z;
+    if (k256::is_zero(z)) k256::set_one(z);
+    k256::mul(acc, acc, z);
+  }
+  FeK256 ai;
+  k256::inv(ai, acc);
+#pragma unroll 1
+  for (int j = cnt - 1; j >= 0; j--) {
+    const size_t i = base + (size_t)j * T;
+    FeK256 z = res[j].z, one, zero; k256::set_one(one); k256::set_zero(zero);
+    const bool zr = k256::is_zero(z);
+    if (zr) z = one;
+    FeK256 zi, t, x, y;
+    k256::mul(zi, ai, pre[j]);
+    k256::mul(ai, ai, z);
+    k256::sqr(t, zi);
+    k256::mul(x, res[j].x, t);
+    k256::mul(t, t, zi);
+    k256::mul(y, res[j].y, t);
+    if (zr) { x = zero; y = zero; }
+    if (out_fmt == FMT_PROJECTIVE) {        // (x : y : 1), identity (0 : 1 : 0)
+      if (zr) y = one;
+      u32* o = out + i * 24;
+      CurveK256::fe_store(o, x); CurveK256::fe_store(o + 8, y);
+      CurveK256::fe_store(o + 16, zr ? zero : one);
+    } else {
+      u32* o = out + i * 16;
+      CurveK256::fe_store(o, x); CurveK256::fe_store(o + 8, y);
+      if (out_inf) out_inf[i] = zr ? 1 : 0;
+    }
+  }
+}
+
+template <int BATCH, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k256_mul_fast_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out,
                                                             int out_fmt, uint8_t* out_inf, size_t n) {
   TabEntryK256 tab[8];
+  K256FastPrep prep;
   JacK256 res[BATCH];
   FeK256 pre[BATCH];
   const size_t T = (size_t)gridDim.x * blockDim.x;
@@ -161,79 +285,11 @@ __global__ void __launch_bounds__(256) k256_mul_fast_kernel(const u32* scalars, 
     for (int j = 0; j < BATCH; j++) {
       const size_t i = base + (size_t)j * T;
       if (i >= n) break;
-      u32 k[8];
-      words_load_be<8>(k, scalars + i * 8);
-      k256::scalar_reduce_once(k);
-      FeK256 px, py, pz;
-      bool p_inf;
-      const u32* src = points + i * pw;
-      k256::from_be_words(px, src);
-      k256::from_be_words(py, src + 8);
-      if (pt_fmt == FMT_PROJECTIVE) {
-        // homogeneous (X:Y:Z) = Jacobian (XZ, YZ^2, Z): run on the curve isomorphic by u = Z
-        k256::from_be_words(pz, src + 16);
-        p_inf = k256::is_zero(pz);
-        FeK256 zz;
-        k256::mul(px, px, pz);
-        k256::sqr(zz, pz);
-        k256::mul(py, py, zz);
-      } else {
-        u32 z = 0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) z |= src[w];
-        p_inf = (z == 0);
-        k256::set_one(pz);
-      }
-      if (p_inf) {   // keep the arithmetic on a valid point; the result is replaced below
-        PtK256 g; k256::generator(g);
-        px = g.x; py = g.y; k256::set_one(pz);
-      }
-      k256::mul_fast_jac(res[j], px, py, k, tab);
-      k256::mul(res[j].z, res[j].z, pz);
-      FeK256 zero; k256::set_zero(zero);
-      k256::select(res[j].z, p_inf, zero, res[j].z);
+      k256_fast_prep(&prep, tab, scalars + i * 8, points + i * pw, pt_fmt);
+      k256_fast_loop(&res[j], &prep, tab);
       cnt = j + 1;
     }
-    // batched conversion; write results as they are produced
-    {
-      FeK256 acc; k256::set_one(acc);
-#pragma unroll 1
-      for (int j = 0; j < cnt; j++) {
-        pre[j] = acc;
-        FeK256 z = res[j].z, one; k256::set_one(one);
-        k256::select(z, k256::is_zero(z), one, z);
-        k256::mul(acc, acc, z);
-      }
-      FeK256 ai;
-      k256::inv(ai, acc);
-#pragma unroll 1
-      for (int j = cnt - 1; j >= 0; j--) {
-        const size_t i = base + (size_t)j * T;
-        FeK256 z = res[j].z, one, zero; k256::set_one(one); k256::set_zero(zero);
-        const bool zr = k256::is_zero(z);
-        k256::select(z, zr, one, z);
-        FeK256 zi, zi2, zi3, x, y;
-        k256::mul(zi, ai, pre[j]);
-        k256::mul(ai, ai, z);
-        k256::sqr(zi2, zi);
-        k256::mul(zi3, zi2, zi);
-        k256::mul(x, res[j].x, zi2);
-        k256::mul(y, res[j].y, zi3);
-        k256::select(x, zr, zero, x);
-        if (out_fmt == FMT_PROJECTIVE) {
-          // (x : y : 1), identity (0 : 1 : 0)
-          k256::select(y, zr, one, y);
-          u32* o = out + i * 24;
-          CurveK256::fe_store(o, x); CurveK256::fe_store(o + 8, y);
-          CurveK256::fe_store(o + 16, zr ? zero : one);
-        } else {
-          k256::select(y, zr, zero, y);
-          u32* o = out + i * 16;
-          CurveK256::fe_store(o, x); CurveK256::fe_store(o + 8, y);
-          if (out_inf) out_inf[i] = zr ? 1 : 0;
-        }
-      }
-    }
+    k256_fast_finish(res, pre, cnt, base, T, out, out_fmt, out_inf);
   }
 }
 

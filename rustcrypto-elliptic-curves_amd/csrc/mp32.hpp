@@ -128,7 +128,7 @@ struct Acc96 {
 // c += a * b
 ECGPU_HD void mac(Acc96& c, u32 a, u32 b) {
 #if ECGPU_ASM
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+  asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
       : "+v"(c.lo), "+v"(c.hi)
       : "v"(a), "v"(b)
       : "vcc");
@@ -149,7 +149,7 @@ ECGPU_HD void mac2(Acc96& c, u32 a, u32 b) {
 ECGPU_HD void acc_add32(Acc96& c, u32 w) {
 #if ECGPU_ASM
   // a*1 + c: one mad + one addc, cheaper than a three-instruction carry chain
-  asm("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+  asm volatile("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
       : "+v"(c.lo), "+v"(c.hi)
       : "v"(w)
       : "vcc");

@@ -27,67 +27,68 @@ struct TabEntryK256 {   // affine point on the isomorphic curve, with beta*x alo
 
 namespace k256 {
 
-// dbl, a = 0: A = X^2, B = Y^2, C = B^2, D = 4 X B, E = 3 A, X3 = E^2 - 2D, Y3 = E (D - X3) - 8C, Z3 = 2 Y Z
-ECGPU_HD void jac_double(JacK256& r, const JacK256& p) {
-  FeK256 a, b, c, d, e, t;
+// In-place doubling, a = 0 (3M + 4S), ordered for a short live set (at most five field elements):
+// A = X^2, B = Y^2, Z3 = 2 Y Z, D = 4 X B, C = B^2, E = 3 A, X3 = E^2 - 2D, Y3 = E (D - X3) - 8C.
+// Infinity (Z = 0) stays infinity; secp256k1 has no point with Y = 0.
+ECGPU_HD void jac_double(JacK256& p) {
+  FeK256 a, b, t;
   sqr(a, p.x);
   sqr(b, p.y);
-  sqr(c, b);
-  mul(d, p.x, b); dbl(d, d); dbl(d, d);
-  dbl(e, a); add(e, e, a);
-  mul(t, p.y, p.z); dbl(r.z, t);
-  sqr(t, e);
-  FeK256 d2; dbl(d2, d);
-  sub(r.x, t, d2);
-  sub(t, d, r.x); mul(t, e, t);
-  dbl(c, c); dbl(c, c); dbl(c, c);
-  sub(r.y, t, c);
+  mul(p.z, p.y, p.z); dbl(p.z, p.z);        // Z3
+  mul(p.y, p.x, b); dbl(p.y, p.y); dbl(p.y, p.y);   // D (in p.y)
+  sqr(b, b);                                 // C
+  dbl(t, a); add(a, t, a);                   // E (in a)
+  sqr(t, a);
+  sub(t, t, p.y); sub(p.x, t, p.y);          // X3 = E^2 - 2D
+  sub(p.y, p.y, p.x); mul(p.y, a, p.y);      // E (D - X3)
+  dbl(b, b); dbl(b, b); dbl(b, b);           // 8C
+  sub(p.y, p.y, b);
 }
+ECGPU_HD void jac_double(JacK256& r, const JacK256& p) { r = p; jac_double(r); }
 
 // doubling of an affine point (Z = 1)
 ECGPU_HD void jac_double_affine(JacK256& r, const FeK256& x, const FeK256& y) {
-  JacK256 p;
-  p.x = x; p.y = y; set_one(p.z);
-  jac_double(r, p);
+  r.x = x; r.y = y; set_one(r.z);
+  jac_double(r);
 }
 
-// r = p + (x2, y2) for an affine, non-identity (x2, y2).  8M + 3S.  `zr` (optional) receives the
-// ratio Z3 / Z1 = H, which the table construction needs.
-//   P at infinity            -> (x2, y2, 1)
+// In-place p += (x2, y2) for an affine, non-identity (x2, y2).  8M + 3S.  `zr` (optional) receives
+// the ratio Z3 / Z1 = H, which the table construction needs.  Real control flow (not selects) for
+// the special cases so that no second copy of the accumulator has to stay live:
+//   p at infinity            -> (x2, y2, 1)
 //   same x, same y (H=R=0)   -> doubling of (x2, y2)
 //   same x, opposite y       -> Z3 = Z1 * 0 = 0: infinity falls out of the formula
-ECGPU_HD void jac_add_mixed(JacK256& r, const JacK256& p, const FeK256& x2, const FeK256& y2, FeK256* zr) {
-  FeK256 z1z1, u2, s2, h, rr, hh, hhh, v, t;
-  sqr(z1z1, p.z);
-  mul(u2, x2, z1z1);
-  mul(s2, p.z, z1z1); mul(s2, s2, y2);
-  sub(h, u2, p.x);
-  sub(rr, s2, p.y);
-  const bool p_inf = is_zero(p.z);
-  const bool same = is_zero(h) && is_zero(rr) && !p_inf;
-  sqr(hh, h);
-  mul(hhh, hh, h);
-  mul(v, p.x, hh);
-  JacK256 o;
-  sqr(t, rr);
-  sub(t, t, hhh);
-  FeK256 v2; dbl(v2, v);
-  sub(o.x, t, v2);
-  sub(t, v, o.x); mul(t, rr, t);
-  FeK256 yh; mul(yh, p.y, hhh);
-  sub(o.y, t, yh);
-  mul(o.z, p.z, h);
-  if (zr) *zr = h;
-  if (__builtin_expect(same, 0)) {   // never taken for honest GLV digits; kept exact
-    JacK256 d;
-    jac_double_affine(d, x2, y2);
-    select(o.x, same, d.x, o.x); select(o.y, same, d.y, o.y); select(o.z, same, d.z, o.z);
-    if (zr) { FeK256 y2d; dbl(y2d, y2); select(*zr, same, y2d, *zr); }   // not used on that path
+ECGPU_HD void jac_add_mixed(JacK256& p, const FeK256& x2, const FeK256& y2, FeK256* zr) {
+  if (is_zero(p.z)) {
+    p.x = x2; p.y = y2; set_one(p.z);
+    if (zr) set_one(*zr);
+    return;
   }
-  FeK256 one; set_one(one);
-  select(r.x, p_inf, x2, o.x);
-  select(r.y, p_inf, y2, o.y);
-  select(r.z, p_inf, one, o.z);
+  FeK256 h, r, t, u;
+  sqr(t, p.z);                               // Z1Z1
+  mul(h, x2, t);                             // U2
+  mul(t, p.z, t); mul(r, t, y2);             // S2
+  sub(h, h, p.x);                            // H
+  sub(r, r, p.y);                            // R
+  if (__builtin_expect(is_zero(h) && is_zero(r), 0)) {   // never taken for honest GLV digits; kept exact
+    if (zr) dbl(*zr, y2);
+    jac_double_affine(p, x2, y2);
+    return;
+  }
+  if (zr) *zr = h;
+  mul(p.z, p.z, h);                          // Z3
+  sqr(t, h);                                 // HH
+  mul(h, t, h);                              // HHH
+  mul(t, p.x, t);                            // V
+  sqr(u, r);
+  sub(u, u, h); sub(u, u, t); sub(p.x, u, t);    // X3 = R^2 - HHH - 2V
+  sub(t, t, p.x); mul(t, r, t);              // R (V - X3)
+  mul(h, p.y, h);                            // Y1 HHH
+  sub(p.y, t, h);
+}
+ECGPU_HD void jac_add_mixed(JacK256& r, const JacK256& p, const FeK256& x2, const FeK256& y2, FeK256* zr) {
+  r = p;
+  jac_add_mixed(r, x2, y2, zr);
 }
 
 // [P, 2P, .., 8P] with a common denominator.  On return tab[j-1] = (x', beta x', y') are the affine
@@ -122,16 +123,13 @@ ECGPU_HD void table_build_globalz(TabEntryK256* tab, FeK256& zglobal, const FeK2
 // Adds digit d of one GLV half: d in [-8, 8], `lam` selects beta*x, `neg` is the sign of that half.
 ECGPU_HD void add_digit(JacK256& acc, const TabEntryK256* tab, int d, bool lam, bool neg) {
   const int ad = d < 0 ? -d : d;
-  const TabEntryK256& e = tab[ad ? ad - 1 : 0];
-  FeK256 x, y, ny;
-  select(x, lam, e.bx, e.x);
-  neg ^= (d < 0);
-  k256::neg(ny, e.y);
-  select(y, neg, ny, e.y);
-  JacK256 s;
-  jac_add_mixed(s, acc, x, y, nullptr);
-  const bool skip = (ad == 0);
-  select(acc.x, skip, acc.x, s.x); select(acc.y, skip, acc.y, s.y); select(acc.z, skip, acc.z, s.z);
+  if (ad != 0) {
+    const TabEntryK256* e = tab + (ad - 1);
+    FeK256 x = lam ? e->bx : e->x;
+    FeK256 y = e->y;
+    if (neg != (d < 0)) k256::neg(y, y);
+    jac_add_mixed(acc, x, y, nullptr);
+  }
 }
 
 // k * P for an affine, non-identity P; result in Jacobian coordinates on secp256k1.
@@ -149,7 +147,7 @@ ECGPU_HD void mul_fast_jac(JacK256& acc, const FeK256& px, const FeK256& py, con
 #pragma unroll 1
   for (int i = 31; i >= 0; i--) {
 #pragma unroll 1
-    for (int j = 0; j < 4; j++) jac_double(acc, acc);
+    for (int j = 0; j < 4; j++) jac_double(acc);
     u32 w1 = d1.y[0], w2 = d2.y[0];
 #pragma unroll
     for (int q = 1; q < 4; q++) { w1 = (i >> 3) == q ? d1.y[q] : w1; w2 = (i >> 3) == q ? d2.y[q] : w2; }
