@@ -173,7 +173,7 @@ static int lincomb_launch(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fm
   } else if (terms == 1 && C::ID == 0 && !(flags & ECGPU_EXACT_REFERENCE)) {
     // throughput schedule: grid sized so that every lane owns a batch worth of elements when n allows
     // ECGPU_K256_FAST_WAVES (2/3/4) picks the occupancy variant; default chosen from measurements
-    static const int waves = [] { const char* e = getenv("ECGPU_K256_FAST_WAVES"); int w = e ? atoi(e) : 3; return (w < 2 || w > 4) ? 3 : w; }();
+    static const int waves = [] { const char* e = getenv("ECGPU_K256_FAST_WAVES"); int w = e ? atoi(e) : 4; return (w < 2 || w > 4) ? 4 : w; }();
     if (waves == 2)
       hipLaunchKernelGGL((k256_mul_fast_kernel<16, 2>), dim3(grid_for(c, n, 2)), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
     else if (waves == 4)

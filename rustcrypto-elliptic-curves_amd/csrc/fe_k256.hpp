@@ -47,6 +47,7 @@ ECGPU_HD void fold_top(u32* r, u64 T) {
 // r = a * b mod p (weakly reduced).  field_5x52.rs:288-449 (mul_inner) is the reference.
 // Columns 8..14 of the schoolbook product are summed first (H), then columns 0..7 are summed
 // together with H*C, so the pseudo-Mersenne fold rides on the same 96-bit accumulator.
+#ifdef ECGPU_K256_PER_MAC_ASM
 ECGPU_HD void mul(FeK256& r, const FeK256& a, const FeK256& b) {
   u32 h[8];
   Acc96 c{0, 0};
@@ -81,6 +82,45 @@ ECGPU_HD void mul(FeK256& r, const FeK256& a, const FeK256& b) {
   for (int i = 0; i < 8; i++) r.v[i] = t[i];
   fold_top(r.v, T);
 }
+#else
+// One asm statement per column (hipcc pads each asm statement with an s_nop): the column's
+// products, and for the low half also h[k]*977 and h[k-1]*1, go into a single statement.
+template <int K>
+ECGPU_HD void mul_high_column(u32* h, Acc96& c, const u32* a, const u32* b) {
+  mac_product_column<8, K, 0>(c, a, b, nullptr, nullptr);
+  h[K - 8] = acc_pop(c);
+}
+template <int K>
+ECGPU_HD void mul_low_column(u32* t, Acc96& c, const u32* a, const u32* b, const u32* h) {
+  if constexpr (K == 0) {
+    const u32 xa[1] = {h[0]}, xb[1] = {C_LO};
+    mac_product_column<8, K, 1>(c, a, b, xa, xb);
+  } else {
+    const u32 xa[2] = {h[K], h[K - 1]}, xb[2] = {C_LO, 1u};
+    mac_product_column<8, K, 2>(c, a, b, xa, xb);
+  }
+  t[K] = acc_pop(c);
+}
+ECGPU_HD void mul(FeK256& r, const FeK256& a, const FeK256& b) {
+  u32 h[8], t[8];
+  Acc96 c{0, 0};
+  mul_high_column<8>(h, c, a.v, b.v);  mul_high_column<9>(h, c, a.v, b.v);
+  mul_high_column<10>(h, c, a.v, b.v); mul_high_column<11>(h, c, a.v, b.v);
+  mul_high_column<12>(h, c, a.v, b.v); mul_high_column<13>(h, c, a.v, b.v);
+  mul_high_column<14>(h, c, a.v, b.v);
+  h[7] = (u32)c.lo;
+  c.lo = 0; c.hi = 0;
+  mul_low_column<0>(t, c, a.v, b.v, h); mul_low_column<1>(t, c, a.v, b.v, h);
+  mul_low_column<2>(t, c, a.v, b.v, h); mul_low_column<3>(t, c, a.v, b.v, h);
+  mul_low_column<4>(t, c, a.v, b.v, h); mul_low_column<5>(t, c, a.v, b.v, h);
+  mul_low_column<6>(t, c, a.v, b.v, h); mul_low_column<7>(t, c, a.v, b.v, h);
+  // overflow above 2^256: remaining accumulator plus the last shifted word of H
+  const u64 T = c.lo + h[7];
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  fold_top(r.v, T);
+}
+#endif
 
 // reduce a 16-word integer modulo p
 ECGPU_HD void reduce16(FeK256& r, const u32* w) {
@@ -88,9 +128,13 @@ ECGPU_HD void reduce16(FeK256& r, const u32* w) {
   u32 t[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    acc_add32(c, w[k]);
-    mac(c, w[8 + k], C_LO);
-    if (k > 0) acc_add32(c, w[8 + k - 1]);
+    if (k == 0) {
+      const u32 pa[2] = {w[0], w[8]}, pb[2] = {1u, C_LO};
+      mac_cols<2>(c, pa, pb);
+    } else {
+      const u32 pa[3] = {w[k], w[8 + k], w[8 + k - 1]}, pb[3] = {1u, C_LO, 1u};
+      mac_cols<3>(c, pa, pb);
+    }
     t[k] = acc_pop(c);
   }
   const u64 T = c.lo + w[15];
@@ -106,31 +150,37 @@ ECGPU_HD void sqr(FeK256& r, const FeK256& a) {
   reduce16(r, w);
 }
 
-// r = a + b mod p   (field_5x52.rs:264-272 adds limb-wise and defers; here the fold is immediate)
+// r = a + b mod p   (field_5x52.rs:264-272 adds limb-wise and defers; here the fold is immediate).
+// The carry out of 2^256 is folded into words 0 and 1; a carry out of word 1 (probability ~2^-32)
+// takes the rare path that ripples it upwards and, if that wraps again, folds once more.
 ECGPU_HD void add(FeK256& r, const FeK256& a, const FeK256& b) {
-  u32 c = mp_add<8>(r.v, a.v, b.v);
+  const u32 c = mp_add<8>(r.v, a.v, b.v);
   u32 c2 = 0;
   r.v[0] = addc(r.v[0], c ? C_LO : 0u, c2);
   r.v[1] = addc(r.v[1], c, c2);
+  if (__builtin_expect(c2 != 0, 0)) {
 #pragma unroll
-  for (int i = 2; i < 8; i++) r.v[i] = addc(r.v[i], 0u, c2);
-  // second wrap only when both inputs were within C of 2^256; the wrapped value is then < C
-  u32 c3 = 0;
-  r.v[0] = addc(r.v[0], c2 ? C_LO : 0u, c3);
-  r.v[1] = addc(r.v[1], c2, c3);
+    for (int i = 2; i < 8; i++) r.v[i] = addc(r.v[i], 0u, c2);
+    // second wrap only when both inputs were within C of 2^256; the wrapped value is then < C
+    u32 c3 = 0;
+    r.v[0] = addc(r.v[0], c2 ? C_LO : 0u, c3);
+    r.v[1] = addc(r.v[1], c2, c3);
+  }
 }
 
 // r = a - b mod p   (reference: a + negate(b), field.rs:425-451, field_5x52.rs:252-260)
 ECGPU_HD void sub(FeK256& r, const FeK256& a, const FeK256& b) {
-  u32 bw = mp_sub<8>(r.v, a.v, b.v);
+  const u32 bw = mp_sub<8>(r.v, a.v, b.v);
   u32 b2 = 0;
   r.v[0] = subb(r.v[0], bw ? C_LO : 0u, b2);
   r.v[1] = subb(r.v[1], bw, b2);
+  if (__builtin_expect(b2 != 0, 0)) {
 #pragma unroll
-  for (int i = 2; i < 8; i++) r.v[i] = subb(r.v[i], 0u, b2);
-  u32 b3 = 0;
-  r.v[0] = subb(r.v[0], b2 ? C_LO : 0u, b3);
-  r.v[1] = subb(r.v[1], b2, b3);
+    for (int i = 2; i < 8; i++) r.v[i] = subb(r.v[i], 0u, b2);
+    u32 b3 = 0;
+    r.v[0] = subb(r.v[0], b2 ? C_LO : 0u, b3);
+    r.v[1] = subb(r.v[1], b2, b3);
+  }
 }
 
 ECGPU_HD void set_zero(FeK256& r) { mp_zero<8>(r.v); }

@@ -158,6 +158,40 @@ ECGPU_HD void acc_add32(Acc96& c, u32 w) {
   c.hi += (c.lo < w);
 #endif
 }
+
+#include "mp32_cols.inc"
+
+// c += sum_{m < M} pa[m] * pb[m], issued as one asm statement
+template <int M>
+ECGPU_HD void mac_cols(Acc96& c, const u32* pa, const u32* pb) {
+  static_assert(M >= 1 && M <= 12, "column length");
+  if constexpr (M == 1) mac_col1(c, pa[0], pb[0]);
+  if constexpr (M == 2) mac_col2(c, pa[0], pb[0], pa[1], pb[1]);
+  if constexpr (M == 3) mac_col3(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2]);
+  if constexpr (M == 4) mac_col4(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3]);
+  if constexpr (M == 5) mac_col5(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4]);
+  if constexpr (M == 6) mac_col6(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5]);
+  if constexpr (M == 7) mac_col7(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6]);
+  if constexpr (M == 8) mac_col8(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7]);
+  if constexpr (M == 9) mac_col9(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8]);
+  if constexpr (M == 10) mac_col10(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9]);
+  if constexpr (M == 11) mac_col11(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9], pa[10], pb[10]);
+  if constexpr (M == 12) mac_col12(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9], pa[10], pb[10], pa[11], pb[11]);
+}
+// column k of the N x N schoolbook product: sum_{i+j=k} a_i b_j, plus NX extra products (xa, xb)
+template <int N, int K, int NX>
+ECGPU_HD void mac_product_column(Acc96& c, const u32* a, const u32* b, const u32* xa, const u32* xb) {
+  constexpr int LO = (K - (N - 1)) > 0 ? (K - (N - 1)) : 0;
+  constexpr int HI = K < (N - 1) ? K : (N - 1);
+  constexpr int M = HI - LO + 1;
+  u32 pa[M + NX + 1], pb[M + NX + 1];
+#pragma unroll
+  for (int m = 0; m < M; m++) { pa[m] = a[LO + m]; pb[m] = b[K - LO - m]; }
+#pragma unroll
+  for (int m = 0; m < NX; m++) { pa[M + m] = xa[m]; pb[M + m] = xb[m]; }
+  mac_cols<M + NX>(c, pa, pb);
+}
+
 // pop the low word and shift the accumulator down by 32 bits
 ECGPU_HD u32 acc_pop(Acc96& c) {
   u32 r = (u32)c.lo;
@@ -184,21 +218,36 @@ ECGPU_HD void mp_mul_wide(u32* r, const u32* a, const u32* b) {
   r[2 * N - 1] = (u32)c.lo;
 }
 
+
+// column K of the off-diagonal half of a square: sum_{i < j, i + j = K} a_i a_j
+template <int N, int K>
+ECGPU_HD void mac_cross_column(Acc96& c, const u32* a) {
+  constexpr int LO = (K - (N - 1)) > 0 ? (K - (N - 1)) : 0;
+  constexpr int HI = (K - 1) / 2;            // largest i with i < K - i
+  constexpr int M = HI - LO + 1;
+  if constexpr (M >= 1) {
+    u32 pa[M], pb[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) { pa[m] = a[LO + m]; pb[m] = a[K - LO - m]; }
+    mac_cols<M>(c, pa, pb);
+  }
+}
+template <int N, int K>
+ECGPU_HD void sqr_cross_columns(u32* x, Acc96& c, const u32* a) {
+  if constexpr (K < 2 * N - 2) {
+    mac_cross_column<N, K>(c, a);
+    x[K] = acc_pop(c);
+    sqr_cross_columns<N, K + 1>(x, c, a);
+  }
+}
+
 // r[0..2N) = a * a : off-diagonal products once, doubled by a one-bit funnel shift, plus the squares
 template <int N>
 ECGPU_HD void mp_sqr_wide(u32* r, const u32* a) {
   u32 x[2 * N];
   Acc96 c{0, 0};
   x[0] = 0;
-#pragma unroll
-  for (int k = 1; k < 2 * N - 2; k++) {
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      const int j = k - i;
-      if (j > i && j < N) mac(c, a[i], a[j]);
-    }
-    x[k] = acc_pop(c);
-  }
+  sqr_cross_columns<N, 1>(x, c, a);
   x[2 * N - 2] = (u32)c.lo;   // the cross sum is < 2^(64N-1): it fits, top bit clear
   x[2 * N - 1] = (u32)(c.lo >> 32);
   // r = 2*x + sum a_i^2 2^(64 i)
