@@ -1,0 +1,107 @@
+// Generic kernel launchers over a curve traits class; instantiated once per curve in ops_*.hip.
+#pragma once
+#include <stdlib.h>
+#include "ecgpu_internal.hpp"
+#include "kernels.hpp"
+
+namespace ecgpu {
+
+template <class C>
+struct CurveOps {
+  static int field_op(ecgpu_ctx* c, int op, const u32* a, const u32* b, u32* o, size_t n) {
+    const unsigned g = ecgpu_grid_for(c, n, 8);
+    switch (op) {
+#define FOP(OPC) case OPC: hipLaunchKernelGGL((field_op_kernel<C, OPC>), dim3(g), dim3(256), 0, c->stream, a, b, o, n); break;
+      FOP(FE_MUL) FOP(FE_SQR) FOP(FE_ADD) FOP(FE_SUB) FOP(FE_NEG) FOP(FE_INV) FOP(FE_SQRT)
+#undef FOP
+      default: return ecgpu_set_err(c, ECGPU_ERR_ARG, "unknown field op %d", op);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static int point_op(ecgpu_ctx* c, int op, const u32* p, const u32* q, u32* o, size_t n) {
+    const unsigned g = ecgpu_grid_for(c, n, 8);
+    switch (op) {
+      case PT_ADD: hipLaunchKernelGGL((point_op_kernel<C, PT_ADD>), dim3(g), dim3(256), 0, c->stream, p, q, o, n); break;
+      case PT_ADD_MIXED: hipLaunchKernelGGL((point_op_kernel<C, PT_ADD_MIXED>), dim3(g), dim3(256), 0, c->stream, p, q, o, n); break;
+      case PT_DOUBLE: hipLaunchKernelGGL((point_op_kernel<C, PT_DOUBLE>), dim3(g), dim3(256), 0, c->stream, p, q, o, n); break;
+      default: return ecgpu_set_err(c, ECGPU_ERR_ARG, "unknown point op %d", op);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static int normalize(ecgpu_ctx* c, const u32* p, u32* out_xy, uint8_t* out_inf, size_t n) {
+    hipLaunchKernelGGL((normalize_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, p, out_xy, out_inf, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static int ensure_gen_table(ecgpu_ctx* c) {
+    if (c->gen_table[C::ID]) return 0;
+    void* t = nullptr;
+    HIPCHK(c, hipMalloc(&t, sizeof(typename C::Pt) * C::GEN_TABLE_PTS));
+    hipLaunchKernelGGL((gen_table_kernel<C>), dim3(1), dim3(64), 0, c->stream, (typename C::Pt*)t);
+    HIPCHK(c, hipGetLastError());
+    c->gen_table[C::ID] = t;
+    return 0;
+  }
+  // curve-specific throughput kernels hook in here (specialised in ops_*.hip); returns 1 if it launched
+  static int lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt,
+                          uint8_t* out_inf, size_t n);
+  static int lincomb(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt, uint8_t* out_inf,
+                     size_t n, unsigned flags) {
+    if (!(flags & ECGPU_EXACT_REFERENCE)) {
+      int rc = lincomb_fast(c, sc, pts, pt_fmt, terms, out, out_fmt, out_inf, n);
+      if (rc < 0) return rc;
+      if (rc == 1) return 0;
+    }
+    const unsigned g = ecgpu_grid_for(c, n, 4);
+    if (!pts) {
+      if (terms != 1) return ecgpu_set_err(c, ECGPU_ERR_ARG, "generator multiplication takes one term");
+      int rc = ensure_gen_table(c);
+      if (rc) return rc;
+      hipLaunchKernelGGL((mul_gen_ref_kernel<C>), dim3(g), dim3(256), 0, c->stream, sc, (const typename C::Pt*)c->gen_table[C::ID], out,
+                         out_fmt, out_inf, n);
+    } else if (terms == 1) {
+      hipLaunchKernelGGL((lincomb_ref_kernel<C, 1>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
+    } else if (terms == 2) {
+      hipLaunchKernelGGL((lincomb_ref_kernel<C, 2>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
+    } else {
+      return ecgpu_set_err(c, ECGPU_ERR_UNSUPPORTED, "lincomb_batch supports 1 or 2 terms per combination (use ecgpu_msm for large sums)");
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static int msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt);
+  static int validate_scalars(ecgpu_ctx* c, const u32* sc, uint8_t* ok, size_t n) {
+    hipLaunchKernelGGL((validate_scalars_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, sc, ok, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static int validate_points(ecgpu_ctx* c, const u32* xy, uint8_t* ok, size_t n) {
+    hipLaunchKernelGGL((validate_points_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, xy, ok, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static int decompress(ecgpu_ctx* c, const u32* x, const uint8_t* odd, u32* out_xy, uint8_t* ok, size_t n) {
+    hipLaunchKernelGGL((decompress_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, x, odd, out_xy, ok, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static int synth_scalars(ecgpu_ctx* c, uint64_t seed, uint64_t first, u32* out, size_t n) {
+    hipLaunchKernelGGL((synth_scalars_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, (u64)seed, (u64)first, out, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static int synth_points(ecgpu_ctx* c, uint64_t seed, uint64_t first, u32* out, size_t n) {
+    hipLaunchKernelGGL((synth_points_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, (u64)seed, (u64)first, out, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static const ecgpu_curve_ops* table() {
+    static const ecgpu_curve_ops t = {field_op, point_op, normalize, lincomb, msm, validate_scalars, validate_points,
+                                      decompress, synth_scalars, synth_points};
+    return &t;
+  }
+};
+
+}  // namespace ecgpu

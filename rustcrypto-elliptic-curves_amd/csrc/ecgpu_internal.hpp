@@ -1,0 +1,70 @@
+// Shared by the API translation unit (ecgpu.hip) and the per-curve kernel translation units
+// (ops_*.hip): context layout, error helpers and the table of kernel launchers of one curve.
+// Each curve's kernels are compiled in their own translation unit so the library builds in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <mutex>
+
+#include "../../include/ecgpu.h"
+
+struct ecgpu_ctx {
+  int device = -1;
+  int num_cus = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  char err[512] = {0};
+  std::mutex mu;
+  // grow-only device staging buffers for ECGPU_MEM_HOST calls
+  void* stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t stage_cap[6] = {0, 0, 0, 0, 0, 0};
+  // precomputed generator tables, one per curve, built on first use
+  void* gen_table[3] = {nullptr, nullptr, nullptr};
+  // MSM workspace (grow-only)
+  void* msm_ws = nullptr;
+  size_t msm_ws_cap = 0;
+};
+
+static inline int ecgpu_set_err(ecgpu_ctx* c, int code, const char* fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+#define HIPCHK(c, call)                                                                                        \
+  do {                                                                                                         \
+    hipError_t e_ = (call);                                                                                    \
+    if (e_ != hipSuccess) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline unsigned ecgpu_grid_for(const ecgpu_ctx* c, size_t n, int per_cu) {
+  size_t blocks = (n + 255) / 256;
+  size_t cap = (size_t)c->num_cus * per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks == 0) blocks = 1;
+  return (unsigned)blocks;
+}
+
+// Kernel launchers of one curve; all pointers are device pointers, everything is asynchronous on c->stream.
+struct ecgpu_curve_ops {
+  int (*field_op)(ecgpu_ctx* c, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n);
+  int (*point_op)(ecgpu_ctx* c, int op, const uint32_t* p, const uint32_t* q, uint32_t* out, size_t n);
+  int (*normalize)(ecgpu_ctx* c, const uint32_t* p, uint32_t* out_xy, uint8_t* out_inf, size_t n);
+  int (*lincomb)(ecgpu_ctx* c, const uint32_t* scalars, const uint32_t* points, int pt_fmt, size_t terms, uint32_t* out,
+                 int out_fmt, uint8_t* out_inf, size_t n, unsigned flags);
+  int (*msm)(ecgpu_ctx* c, const uint32_t* scalars, const uint32_t* points, int pt_fmt, size_t n, uint32_t* out, int out_fmt);
+  int (*validate_scalars)(ecgpu_ctx* c, const uint32_t* scalars, uint8_t* ok, size_t n);
+  int (*validate_points)(ecgpu_ctx* c, const uint32_t* xy, uint8_t* ok, size_t n);
+  int (*decompress)(ecgpu_ctx* c, const uint32_t* x, const uint8_t* y_is_odd, uint32_t* out_xy, uint8_t* ok, size_t n);
+  int (*synth_scalars)(ecgpu_ctx* c, uint64_t seed, uint64_t first, uint32_t* out, size_t n);
+  int (*synth_points)(ecgpu_ctx* c, uint64_t seed, uint64_t first, uint32_t* out_xy, size_t n);
+};
+const ecgpu_curve_ops* ecgpu_ops_k256();
+const ecgpu_curve_ops* ecgpu_ops_p256();
+const ecgpu_curve_ops* ecgpu_ops_p384();

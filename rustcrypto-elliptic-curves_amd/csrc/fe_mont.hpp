@@ -1,0 +1,214 @@
+// Montgomery base fields for NIST P-256 and P-384 on saturated 32-bit limbs (8 / 12 VGPRs).
+//
+// Same internal form as the reference: elements are kept as a*R mod p with R = 2^(32 N), always
+// fully reduced (p256/src/arithmetic/field.rs:43 "always in Montgomery form", R = 2^256;
+// p384/src/arithmetic/field.rs:47-63 via fiat_p384_* with R = 2^384).  Both primes are
+// congruent to -1 modulo 2^32, so the Montgomery constant is 1 for 32-bit words and the
+// reduction needs no multiplication to find its quotient digits: in the finely integrated
+// product scanning below the quotient digit of column k is simply the low word of that column.
+// Multiples of the modulus are added column-wise with the same 96-bit accumulator as the
+// product; limbs of p that are zero are skipped at compile time (p256: 4 of 8, p384: 2 of 12).
+// Reference algorithms: p256 field.rs:240-277 (montgomery_reduce) + :293-319 (multiply);
+// p384 p384_64.rs:146 (fiat_p384_mul: the same word-by-word Montgomery, 64-bit words).
+#pragma once
+#include "mp32.hpp"
+
+namespace ecgpu {
+
+struct P256Mod {
+  static constexpr int N = 8;
+  // p = 2^256 - 2^224 + 2^192 + 2^96 - 1   (p256/src/arithmetic/field.rs:22)
+  static constexpr u32 P[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000001u, 0xFFFFFFFFu};
+  // R^2 mod p (field.rs:33-36), R mod p (field.rs:28-31)
+  static constexpr u32 R2[8] = {0x00000003u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFBu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFDu, 0x00000004u};
+  static constexpr u32 ONE[8] = {0x00000001u, 0x00000000u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFEu, 0x00000000u};
+};
+struct P384Mod {
+  static constexpr int N = 12;
+  // p = 2^384 - 2^128 - 2^96 + 2^32 - 1   (p384/src/arithmetic/field.rs:43-45)
+  static constexpr u32 P[12] = {0xFFFFFFFFu, 0x00000000u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFEu, 0xFFFFFFFFu,
+                                0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  // R^2 mod p = 2^768 mod p, R mod p = 2^384 mod p = 2^128 + 2^96 - 2^32 + 1
+  static constexpr u32 R2[12] = {0x00000001u, 0xFFFFFFFEu, 0x00000000u, 0x00000002u, 0x00000000u, 0xFFFFFFFEu,
+                                 0x00000000u, 0x00000002u, 0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u};
+  static constexpr u32 ONE[12] = {0x00000001u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0x00000001u, 0x00000000u,
+                                  0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u};
+};
+
+template <class M>
+struct FeMont {
+  static constexpr int N = M::N;
+  u32 v[M::N];
+};
+
+namespace mont {
+
+// number of non-zero limbs p_j with j in [lo, hi]
+template <class M>
+constexpr int nz_count(int lo, int hi) {
+  int c = 0;
+  for (int j = lo; j <= hi; j++) if (j >= 1 && j < M::N && M::P[j] != 0) c++;
+  return c;
+}
+
+// One column of the finely integrated product scanning:
+//   c += sum_{i+j=K} a_i b_j  +  sum_{i+j=K, j>=1, p_j != 0} m_i p_j   (+ m_{K-1} for the p_0 = -1 term)
+template <class M, int K>
+ECGPU_HD void fips_column(Acc96& c, const u32* a, const u32* b, const u32* m) {
+  constexpr int N = M::N;
+  constexpr int LO = (K - (N - 1)) > 0 ? (K - (N - 1)) : 0;     // first i of the a*b products
+  constexpr int HI = K < (N - 1) ? K : (N - 1);
+  constexpr int NPROD = HI - LO + 1;
+  // quotient digits available: m_0 .. m_{min(K-1, N-1)}; term m_i p_{K-i} needs 1 <= K-i <= N-1
+  constexpr int ILO = (K - (N - 1)) > 0 ? (K - (N - 1)) : 0;
+  constexpr int IHI = (K - 1) < (N - 1) ? (K - 1) : (N - 1);
+  constexpr int NRED = (IHI >= ILO) ? nz_count<M>(K - IHI, K - ILO) : 0;
+  constexpr int NCARRY = (K >= 1 && K <= N) ? 1 : 0;             // m_{K-1} * 2^32 from the p_0 = 2^32 - 1 term
+  constexpr int TOT = NPROD + NRED + NCARRY;
+  u32 pa[TOT > 0 ? TOT : 1], pb[TOT > 0 ? TOT : 1];
+  int n = 0;
+#pragma unroll
+  for (int i = LO; i <= HI; i++) { pa[n] = a[i]; pb[n] = b[K - i]; n++; }
+#pragma unroll
+  for (int i = ILO; i <= IHI; i++) {
+    if (M::P[K - i] != 0) { pa[n] = m[i]; pb[n] = M::P[K - i]; n++; }
+  }
+  if (NCARRY) { pa[n] = m[K - 1]; pb[n] = 1u; n++; }
+  mac_cols<TOT>(c, pa, pb);
+}
+
+template <class M, int K>
+ECGPU_HD void fips_low(Acc96& c, const u32* a, const u32* b, u32* m) {
+  if constexpr (K < M::N) {
+    fips_column<M, K>(c, a, b, m);
+    // m_K = low word; adding m_K * p_0 = m_K 2^32 - m_K clears it and carries m_K into the next
+    // column (done there as an (m_K, 1) product): popping the word is all that happens here
+    m[K] = acc_pop(c);
+    fips_low<M, K + 1>(c, a, b, m);
+  }
+}
+template <class M, int K>
+ECGPU_HD void fips_high(Acc96& c, const u32* a, const u32* b, const u32* m, u32* t) {
+  if constexpr (K < 2 * M::N - 1) {
+    fips_column<M, K>(c, a, b, m);
+    t[K - M::N] = acc_pop(c);
+    fips_high<M, K + 1>(c, a, b, m, t);
+  }
+}
+
+// r = a * b * R^-1 mod p
+template <class M>
+ECGPU_HD void mul(FeMont<M>& r, const FeMont<M>& a, const FeMont<M>& b) {
+  constexpr int N = M::N;
+  u32 m[N], t[N + 1];
+  Acc96 c{0, 0};
+  fips_low<M, 0>(c, a.v, b.v, m);
+  fips_high<M, N>(c, a.v, b.v, m, t);
+  t[N - 1] = (u32)c.lo;
+  t[N] = (u32)(c.lo >> 32);
+  // t < 2p: subtract p once if needed (p256 field.rs:272-276 sub_inner)
+  u32 d[N], bw = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) d[i] = subb(t[i], M::P[i], bw);
+  const bool use_d = (t[N] != 0) || (bw == 0);
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = use_d ? d[i] : t[i];
+}
+template <class M>
+ECGPU_HD void sqr(FeMont<M>& r, const FeMont<M>& a) { mul(r, a, a); }
+
+template <class M>
+ECGPU_HD void add(FeMont<M>& r, const FeMont<M>& a, const FeMont<M>& b) {   // p256 field.rs:118-134
+  constexpr int N = M::N;
+  u32 t[N], d[N];
+  const u32 c = mp_add<N>(t, a.v, b.v);
+  u32 bw = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) d[i] = subb(t[i], M::P[i], bw);
+  const bool use_d = (c != 0) || (bw == 0);
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = use_d ? d[i] : t[i];
+}
+template <class M>
+ECGPU_HD void sub(FeMont<M>& r, const FeMont<M>& a, const FeMont<M>& b) {   // p256 field.rs:142-197
+  constexpr int N = M::N;
+  u32 t[N];
+  const u32 bw = mp_sub<N>(t, a.v, b.v);
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = addc(t[i], bw ? M::P[i] : 0u, c);
+}
+template <class M> ECGPU_HD void set_zero(FeMont<M>& r) { mp_zero<M::N>(r.v); }
+template <class M> ECGPU_HD void set_one(FeMont<M>& r) {
+#pragma unroll
+  for (int i = 0; i < M::N; i++) r.v[i] = M::ONE[i];
+}
+template <class M> ECGPU_HD void neg(FeMont<M>& r, const FeMont<M>& a) { FeMont<M> z; set_zero(z); sub(r, z, a); }
+template <class M> ECGPU_HD void dbl(FeMont<M>& r, const FeMont<M>& a) { add(r, a, a); }
+template <class M> ECGPU_HD bool is_zero(const FeMont<M>& a) { return mp_is_zero<M::N>(a.v); }
+template <class M> ECGPU_HD bool equal(const FeMont<M>& a, const FeMont<M>& b) { return mp_eq<M::N>(a.v, b.v); }
+template <class M> ECGPU_HD void select(FeMont<M>& r, bool c, const FeMont<M>& a, const FeMont<M>& b) { mp_select<M::N>(r.v, c, a.v, b.v); }
+
+// canonical integer (little-endian limbs, < p) <-> Montgomery form
+template <class M>
+ECGPU_HD void to_mont(FeMont<M>& r, const u32* canon) {   // p256 field.rs:288-290
+  FeMont<M> x, r2;
+#pragma unroll
+  for (int i = 0; i < M::N; i++) { x.v[i] = canon[i]; r2.v[i] = M::R2[i]; }
+  mul(r, x, r2);
+}
+template <class M>
+ECGPU_HD void from_mont(u32* canon, const FeMont<M>& a) {   // p256 field.rs:281-284
+  FeMont<M> one, t;
+  set_zero(one); one.v[0] = 1;
+  mul(t, a, one);
+#pragma unroll
+  for (int i = 0; i < M::N; i++) canon[i] = t.v[i];
+}
+
+template <class M>
+ECGPU_HD void sqr_n(FeMont<M>& r, const FeMont<M>& a, int n) {
+  r = a;
+  for (int i = 0; i < n; i++) sqr(r, r);
+}
+// r = a^e for a public exponent e (little-endian limbs), square-and-multiply from the top bit
+template <class M>
+ECGPU_HD void pow_public(FeMont<M>& r, const FeMont<M>& a, const u32* e) {
+  FeMont<M> acc;
+  set_one(acc);
+#pragma unroll 1
+  for (int i = 32 * M::N - 1; i >= 0; i--) {
+    sqr(acc, acc);
+    if ((e[i >> 5] >> (i & 31)) & 1) mul(acc, acc, a);
+  }
+  r = acc;
+}
+// a^(p-2): the unique inverse (p256 field.rs:357-382 uses a fixed chain for the same exponent;
+// p384 uses Bernstein-Yang, p384 field.rs:67-91 - the result is the same field element)
+template <class M>
+ECGPU_HD void inv(FeMont<M>& r, const FeMont<M>& a) {
+  u32 e[M::N];
+#pragma unroll
+  for (int i = 0; i < M::N; i++) e[i] = M::P[i];
+  e[0] -= 2;
+  pow_public(r, a, e);
+}
+// a^((p+1)/4) (both primes are 3 mod 4); returns whether it is a square root
+// (p256 field.rs:385-411, p384 field.rs:95-117)
+template <class M>
+ECGPU_HD bool sqrt(FeMont<M>& r, const FeMont<M>& a) {
+  u32 e[M::N + 1];
+  u32 c = 1;
+#pragma unroll
+  for (int i = 0; i < M::N; i++) e[i] = addc(M::P[i], 0u, c);
+  e[M::N] = c;
+#pragma unroll
+  for (int i = 0; i < M::N; i++) e[i] = (e[i] >> 2) | (e[i + 1] << 30);
+  pow_public(r, a, e);
+  FeMont<M> chk;
+  sqr(chk, r);
+  return equal(chk, a);
+}
+
+}  // namespace mont
+}  // namespace ecgpu

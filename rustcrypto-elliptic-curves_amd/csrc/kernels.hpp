@@ -301,11 +301,12 @@ __global__ void gen_table_kernel(typename C::Pt* tab) {
 template <class C>
 __global__ void __launch_bounds__(256) mul_gen_ref_kernel(const u32* scalars, const typename C::Pt* gen_tab, u32* out,
                                                           int out_fmt, uint8_t* out_inf, size_t n) {
+  typename C::Pt tab[C::ID == 0 ? 1 : C::REF_TABLE_PTS];   // scratch for curves whose mul_by_generator is G * k
   ECGPU_GRID_STRIDE(i, n) {
     u32 k[C::NW];
     C::scalar_load(k, scalars + i * C::NW);
     typename C::Pt r;
-    C::mul_gen_ref(r, k, gen_tab);
+    C::mul_gen_ref(r, k, gen_tab, tab);
     if (out_fmt == FMT_PROJECTIVE) store_projective<C>(out + i * 3 * C::NW, r);
     else store_affine_from_projective<C>(out + i * 2 * C::NW, out_inf ? out_inf + i : nullptr, r);
   }

@@ -164,7 +164,11 @@ ECGPU_HD void acc_add32(Acc96& c, u32 w) {
 // c += sum_{m < M} pa[m] * pb[m], issued as one asm statement
 template <int M>
 ECGPU_HD void mac_cols(Acc96& c, const u32* pa, const u32* pb) {
-  static_assert(M >= 1 && M <= 12, "column length");
+  static_assert(M >= 1, "column length");
+  if constexpr (M > 12) {            // an asm statement takes at most 30 operands: split long columns
+    mac_cols<12>(c, pa, pb);
+    mac_cols<M - 12>(c, pa + 12, pb + 12);
+  }
   if constexpr (M == 1) mac_col1(c, pa[0], pb[0]);
   if constexpr (M == 2) mac_col2(c, pa[0], pb[0], pa[1], pb[1]);
   if constexpr (M == 3) mac_col3(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2]);

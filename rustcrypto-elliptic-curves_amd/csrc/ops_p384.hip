@@ -1,0 +1,13 @@
+// NIST P384 kernels and launchers (one translation unit per curve: the library builds in parallel).
+#include "curve_ops.hpp"
+using namespace ecgpu;
+
+template <>
+int CurveOps<CurveP384>::lincomb_fast(ecgpu_ctx*, const u32*, const u32*, int, size_t, u32*, int, uint8_t*, size_t) {
+  return 0;   // reference schedule only for now
+}
+template <>
+int CurveOps<CurveP384>::msm(ecgpu_ctx* c, const u32*, const u32*, int, size_t, u32*, int) {
+  return ecgpu_set_err(c, ECGPU_ERR_UNSUPPORTED, "ecgpu_msm: k256 only");
+}
+const ecgpu_curve_ops* ecgpu_ops_p384() { return CurveOps<CurveP384>::table(); }

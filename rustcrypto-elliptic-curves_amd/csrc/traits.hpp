@@ -3,6 +3,7 @@
 // (FieldElement ops, ProjectivePoint::{add, add_mixed, double}, Mul<Scalar>, MulByGenerator).
 #pragma once
 #include "mul_k256.hpp"
+#include "curve_nist.hpp"
 
 namespace ecgpu {
 
@@ -67,7 +68,71 @@ struct CurveK256 {
   template <int NT>
   static ECGPU_HD void lincomb_ref(Pt& r, const Pt* p, const u32 (*k)[8], Pt* tab) { k256::lincomb_ref<NT>(r, p, k, tab); }
   static ECGPU_HD void gen_table_build(Pt* tab) { Pt g; k256::generator(g); k256::gen_table_build(tab, g); }
-  static ECGPU_HD void mul_gen_ref(Pt& r, const u32* k, const Pt* gen_tab) { k256::mul_gen_ref(r, k, gen_tab); }
+  static ECGPU_HD void mul_gen_ref(Pt& r, const u32* k, const Pt* gen_tab, Pt*) { k256::mul_gen_ref(r, k, gen_tab); }
 };
+
+
+// NIST curves through the primeorder layer: Montgomery field, RCB a = -3, 4-bit window.
+template <class P>
+struct CurveNist {
+  static constexpr int ID = P::ID;
+  static constexpr int NW = P::Mod::N;
+  static constexpr int NB = 4 * NW;
+  static constexpr int REF_TABLE_PTS = 16;
+  static constexpr int GEN_TABLE_PTS = 1;       // mul_by_generator is G * k (primeorder/src/projective.rs:422-431)
+  using Mod = typename P::Mod;
+  using Fe = FeMont<Mod>;
+  using Pt = PtNist<P>;
+  using Af = AfNist<P>;
+
+  static ECGPU_HD void fe_load(Fe& r, const u32* be) { u32 c[NW]; words_load_be<NW>(c, be); mont::to_mont<Mod>(r, c); }
+  static ECGPU_HD void fe_store(u32* be, const Fe& a) { u32 c[NW]; mont::from_mont<Mod>(c, a); words_store_be<NW>(be, c); }
+  static ECGPU_HD void fe_mul(Fe& r, const Fe& a, const Fe& b) { mont::mul(r, a, b); }
+  static ECGPU_HD void fe_sqr(Fe& r, const Fe& a) { mont::sqr(r, a); }
+  static ECGPU_HD void fe_add(Fe& r, const Fe& a, const Fe& b) { mont::add(r, a, b); }
+  static ECGPU_HD void fe_sub(Fe& r, const Fe& a, const Fe& b) { mont::sub(r, a, b); }
+  static ECGPU_HD void fe_neg(Fe& r, const Fe& a) { mont::neg(r, a); }
+  static ECGPU_HD void fe_inv(Fe& r, const Fe& a) { mont::inv(r, a); }
+  static ECGPU_HD bool fe_sqrt(Fe& r, const Fe& a) { return mont::sqrt(r, a); }
+  static ECGPU_HD bool fe_is_zero(const Fe& a) { return mont::is_zero(a); }
+  static ECGPU_HD bool fe_is_odd(const Fe& a) { u32 c[NW]; mont::from_mont<Mod>(c, a); return c[0] & 1; }   // p256 field.rs:109-112
+  static ECGPU_HD void fe_zero(Fe& r) { mont::set_zero(r); }
+  static ECGPU_HD void fe_one(Fe& r) { mont::set_one(r); }
+  static ECGPU_HD void fe_select(Fe& r, bool c, const Fe& a, const Fe& b) { mont::select(r, c, a, b); }
+  static ECGPU_HD void curve_rhs(Fe& r, const Fe& x) { nist::curve_rhs<P>(r, x); }
+
+  static ECGPU_HD void pt_identity(Pt& r) { nist::pt_identity<P>(r); }
+  static ECGPU_HD void pt_add(Pt& r, const Pt& p, const Pt& q) { nist::pt_add<P>(r, p, q); }
+  static ECGPU_HD void pt_add_mixed(Pt& r, const Pt& p, const Af& q) { nist::pt_add_mixed<P>(r, p, q); }
+  static ECGPU_HD void pt_double(Pt& r, const Pt& p) { nist::pt_double<P>(r, p); }
+  static ECGPU_HD void pt_generator(Pt& g) { nist::pt_generator<P>(g); }
+
+  static ECGPU_HD void scalar_load(u32* k, const u32* be) { words_load_be<NW>(k, be); }
+  static ECGPU_HD void order(u32* n) {
+#pragma unroll
+    for (int i = 0; i < NW; i++) n[i] = P::ORDER[i];
+  }
+  static ECGPU_HD void modulus(u32* p) {
+#pragma unroll
+    for (int i = 0; i < NW; i++) p[i] = Mod::P[i];
+  }
+
+  static ECGPU_HD void mul_ref(Pt& r, const Pt& p, const u32* k, Pt* tab) { nist::mul_ref<P>(r, p, k, tab); }
+  // LinearCombination default: x*k + y*l (primeorder/src/projective.rs:415-420)
+  template <int NT>
+  static ECGPU_HD void lincomb_ref(Pt& r, const Pt* p, const u32 (*k)[NW], Pt* tab) {
+    nist::mul_ref<P>(r, p[0], k[0], tab);
+#pragma unroll 1
+    for (int t = 1; t < NT; t++) {
+      Pt s;
+      nist::mul_ref<P>(s, p[t], k[t], tab);
+      nist::pt_add<P>(r, r, s);
+    }
+  }
+  static ECGPU_HD void gen_table_build(Pt* tab) { nist::pt_generator<P>(tab[0]); }
+  static ECGPU_HD void mul_gen_ref(Pt& r, const u32* k, const Pt* gen_tab, Pt* tab) { nist::mul_ref<P>(r, gen_tab[0], k, tab); }
+};
+using CurveP256 = CurveNist<P256Params>;
+using CurveP384 = CurveNist<P384Params>;
 
 }  // namespace ecgpu

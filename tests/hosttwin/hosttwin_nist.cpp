@@ -1,0 +1,75 @@
+// TEST-ONLY host build of the NIST (primeorder) templates through the curve traits.
+#include <string.h>
+#include <stdlib.h>
+#include "traits.hpp"
+using namespace ecgpu;
+
+template <class C> static void load(typename C::Fe& f, const uint8_t* b) { u32 w[C::NW]; memcpy(w, b, C::NB); C::fe_load(f, w); }
+template <class C> static void store(uint8_t* b, const typename C::Fe& f) { u32 w[C::NW]; C::fe_store(w, f); memcpy(b, w, C::NB); }
+template <class C> static void load_pt(typename C::Pt& p, const uint8_t* b) { load<C>(p.x, b); load<C>(p.y, b + C::NB); load<C>(p.z, b + 2 * C::NB); }
+template <class C> static void store_pt(uint8_t* b, const typename C::Pt& p) { store<C>(b, p.x); store<C>(b + C::NB, p.y); store<C>(b + 2 * C::NB, p.z); }
+
+template <class C>
+static int fe_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, int n) {
+  for (int i = 0; i < n; i++) {
+    typename C::Fe x, y, r; load<C>(x, a + C::NB * i); if (b) load<C>(y, b + C::NB * i);
+    int ok = 1;
+    switch (op) {
+      case 0: C::fe_mul(r, x, y); break;
+      case 1: C::fe_sqr(r, x); break;
+      case 2: C::fe_add(r, x, y); break;
+      case 3: C::fe_sub(r, x, y); break;
+      case 4: C::fe_neg(r, x); break;
+      case 5: C::fe_inv(r, x); break;
+      case 6: ok = C::fe_sqrt(r, x); break;
+      default: return -1;
+    }
+    store<C>(out + C::NB * i, r);
+    if (op == 6 && !ok) memset(out + C::NB * i, 0xFF, C::NB);
+  }
+  return 0;
+}
+template <class C>
+static int pt_op(int op, const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
+  for (int i = 0; i < n; i++) {
+    typename C::Pt a, b, r; load_pt<C>(a, p + 3 * C::NB * i);
+    switch (op) {
+      case 0: load_pt<C>(b, q + 3 * C::NB * i); C::pt_add(r, a, b); break;
+      case 1: {
+        typename C::Af m; const uint8_t* s = q + (2 * C::NB + 1) * i;
+        load<C>(m.x, s); load<C>(m.y, s + C::NB); m.inf = s[2 * C::NB];
+        C::pt_add_mixed(r, a, m); break;
+      }
+      case 2: C::pt_double(r, a); break;
+      default: return -1;
+    }
+    store_pt<C>(out + 3 * C::NB * i, r);
+  }
+  return 0;
+}
+template <class C>
+static int mul_ref(const uint8_t* pts, const uint8_t* ks, uint8_t* out, int n, int gen) {
+  typename C::Pt* tab = (typename C::Pt*)malloc(sizeof(typename C::Pt) * 16);
+  typename C::Pt g; C::pt_generator(g);
+  for (int i = 0; i < n; i++) {
+    typename C::Pt p, r;
+    if (gen) p = g; else load_pt<C>(p, pts + 3 * C::NB * i);
+    u32 w[C::NW], k[C::NW]; memcpy(w, ks + C::NB * i, C::NB); C::scalar_load(k, w);
+    C::mul_ref(r, p, k, tab);
+    store_pt<C>(out + 3 * C::NB * i, r);
+  }
+  free(tab);
+  return 0;
+}
+
+extern "C" {
+int ht_nist_fe_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, int n) {
+  return curve == 1 ? fe_op<CurveP256>(op, a, b, out, n) : fe_op<CurveP384>(op, a, b, out, n);
+}
+int ht_nist_pt_op(int curve, int op, const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
+  return curve == 1 ? pt_op<CurveP256>(op, p, q, out, n) : pt_op<CurveP384>(op, p, q, out, n);
+}
+int ht_nist_mul_ref(int curve, const uint8_t* pts, const uint8_t* ks, uint8_t* out, int n, int gen) {
+  return curve == 1 ? mul_ref<CurveP256>(pts, ks, out, n, gen) : mul_ref<CurveP384>(pts, ks, out, n, gen);
+}
+}

@@ -1,0 +1,202 @@
+"""GPU parity tests for P-256 / P-384 through the C ABI against the oracle and the golden fixtures
+(the reference's own test macros: primeorder/src/dev.rs:66-155 via p256|p384/tests/projective.rs)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import coracle as CO
+from oracle import ecmodel as M
+from oracle import synth
+from conftest import load_config1
+
+pytestmark = pytest.mark.gpu
+CURVES = ["p256", "p384"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ecgpu
+    c = ecgpu.Context(0)
+    yield c
+    c.close()
+
+
+def arr(rows, w):
+    return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(-1, w).copy()
+
+
+def fe_arr(c, vals):
+    return arr([int(v).to_bytes(c.nbytes, "big") for v in vals], c.nbytes)
+
+
+def ints(a):
+    return [int.from_bytes(bytes(r), "big") for r in a]
+
+
+def rand_proj(c, rng, n, start=0):
+    out = []
+    for i in range(n):
+        x, y = synth.point(c, start + i, seed=91)
+        z = rng.randrange(1, c.p)
+        out.append((x * z % c.p, y * z % c.p, z))
+    return out
+
+
+@pytest.mark.parametrize("cn", CURVES)
+def test_field_ops(ctx, cn, ref_vectors):
+    import ecgpu
+    c = M.CURVES[cn]
+    cv = ctx.curve(cn)
+    p = c.p
+    rng = random.Random(51)
+    edge = [0, 1, 2, 3, p - 1, p - 2, 2**32 - 1, 2**32, 2**96, (p - 1) // 2, p >> 1]
+    xs = [a for a in edge for _ in edge] + [rng.randrange(p) for _ in range(2048)]
+    ys = [b for _ in edge for b in edge] + [rng.randrange(p) for _ in range(2048)]
+    a, b = fe_arr(c, xs), fe_arr(c, ys)
+    assert ints(cv.field_op(ecgpu.FE_MUL, a, b)) == [x * y % p for x, y in zip(xs, ys)]
+    assert ints(cv.field_op(ecgpu.FE_ADD, a, b)) == [(x + y) % p for x, y in zip(xs, ys)]
+    assert ints(cv.field_op(ecgpu.FE_SUB, a, b)) == [(x - y) % p for x, y in zip(xs, ys)]
+    assert ints(cv.field_op(ecgpu.FE_SQR, a)) == [x * x % p for x in xs]
+    assert ints(cv.field_op(ecgpu.FE_NEG, a)) == [(-x) % p for x in xs]
+    inv = ints(cv.field_op(ecgpu.FE_INV, a[:300]))
+    assert all((x == 0 and g == 0) or g * x % p == 1 for x, g in zip(xs, inv))
+    sq = ints(cv.field_op(ecgpu.FE_SQRT, a[:300]))
+    for x, g in zip(xs, sq):
+        want = M.field_sqrt(c, x)
+        assert g == ((1 << (8 * c.nbytes)) - 1 if want is None else want)
+    if cn == "p256":
+        dbl = [int(v, 16) for v in ref_vectors["p256"]["field_dbl"]]
+        assert ints(cv.field_op(ecgpu.FE_ADD, fe_arr(c, dbl[:-1]), fe_arr(c, dbl[:-1]))) == dbl[1:]
+
+
+@pytest.mark.parametrize("cn", CURVES)
+def test_point_ops_exact_xyz(ctx, cn):
+    c = M.CURVES[cn]
+    cv = ctx.curve(cn)
+    rng = random.Random(52)
+    ps = rand_proj(c, rng, 200) + [M.IDENTITY, c.G, M.point_neg(c, c.G), c.G, M.IDENTITY]
+    qs = rand_proj(c, rng, 200, 1000) + [c.G, M.IDENTITY, c.G, c.G, M.IDENTITY]
+    w = 3 * c.nbytes
+    pa, qa = arr([M.proj_bytes(c, p) for p in ps], w), arr([M.proj_bytes(c, q) for q in qs], w)
+    assert bytes(cv.add(pa, qa)) == b"".join(M.proj_bytes(c, M.am3_add(c, p, q)) for p, q in zip(ps, qs))
+    assert bytes(cv.double(pa)) == b"".join(M.proj_bytes(c, M.am3_double(c, p)) for p in ps)
+    aff = [M.to_affine(c, q) for q in qs]
+    qaff = arr([M.i2b(c, a[0]) + M.i2b(c, a[1]) for a in aff], 2 * c.nbytes)
+    assert bytes(cv.add_mixed(pa, qaff)) == b"".join(M.proj_bytes(c, M.am3_add_mixed(c, p, a)) for p, a in zip(ps, aff))
+    xy, inf = cv.batch_normalize(pa)
+    for i, p in enumerate(ps):
+        assert bytes(xy[i]) + bytes([inf[i]]) == M.affine_bytes(c, M.to_affine(c, p))
+
+
+@pytest.mark.parametrize("cn", CURVES)
+def test_reference_vectors(ctx, cn, ref_vectors):
+    """group.rs ADD/MUL vectors, ecdsa.rs d->Q / k->r, hash2curve Q0+Q1=P."""
+    c = M.CURVES[cn]
+    cv = ctx.curve(cn)
+    nb = c.nbytes
+    vec = ref_vectors[cn]["group"]["mul"]
+    ks = arr([bytes.fromhex(k) for k, _, _ in vec], nb)
+    xy, inf = cv.mul_by_generator(ks)
+    assert bytes(xy) == b"".join(bytes.fromhex(x + y) for _, x, y in vec) and not inf.any()
+    acc = arr([M.proj_bytes(c, M.IDENTITY)], 3 * nb)
+    gp = arr([M.proj_bytes(c, c.G)], 3 * nb)
+    ga = arr([M.i2b(c, c.gx) + M.i2b(c, c.gy)], 2 * nb)
+    accm = acc.copy()
+    for x, y in ref_vectors[cn]["group"]["add"]:
+        acc = cv.add(acc, gp)
+        accm = cv.add_mixed(accm, ga)
+        for a in (acc, accm):
+            o, i = cv.batch_normalize(a)
+            assert bytes(o[0]).hex() == (x + y).lower() and i[0] == 0
+    ev = ref_vectors[cn]["ecdsa"]
+    xy, _ = cv.mul_by_generator(arr([bytes.fromhex(v["d"]) for v in ev] + [bytes.fromhex(v["k"]) for v in ev], nb))
+    for i, v in enumerate(ev):
+        assert bytes(xy[i]).hex() == v["q_x"] + v["q_y"]
+        assert int.from_bytes(bytes(xy[len(ev) + i][:nb]), "big") % c.n == int(v["r"], 16)
+    for v in ref_vectors[cn]["hash2curve"]:
+        q0 = (int(v["q0_x"], 16), int(v["q0_y"], 16), 1)
+        q1 = (int(v["q1_x"], 16), int(v["q1_y"], 16), 1)
+        o, _ = cv.batch_normalize(cv.add(arr([M.proj_bytes(c, q0)], 3 * nb), arr([M.proj_bytes(c, q1)], 3 * nb)))
+        assert bytes(o[0]).hex() == v["p_x"] + v["p_y"]
+
+
+@pytest.mark.parametrize("cn", CURVES)
+def test_config1_fixture_and_exact_xyz(ctx, cn):
+    import ecgpu
+    c = M.CURVES[cn]
+    cv = ctx.curve(cn)
+    nb = c.nbytes
+    fx = load_config1(cn)
+    ks = arr([bytes.fromhex(r[0]) for r in fx["rows"]], nb)
+    pts = arr([bytes.fromhex(r[1] + r[2]) for r in fx["rows"]], 2 * nb)
+    xy, inf = cv.mul(ks, pts)
+    assert b"".join(bytes(xy[i]) + bytes([inf[i]]) for i in range(len(xy))) == b"".join(bytes.fromhex(r[3]) for r in fx["rows"])
+    rng = random.Random(53)
+    sc = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2] * 2 + [rng.randrange(c.n) for _ in range(20)]
+    ps = [c.G] * 6 + [M.IDENTITY] * 3 + [M.point_neg(c, c.G)] * 3 + rand_proj(c, rng, 20, 3000)
+    out = cv.mul(fe_arr(c, sc), arr([M.proj_bytes(c, p) for p in ps], 3 * nb), point_format=ecgpu.PROJECTIVE,
+                 out_format=ecgpu.PROJECTIVE, flags=ecgpu.EXACT_REFERENCE)
+    for i, (p, k) in enumerate(zip(ps, sc)):
+        assert bytes(out[i]) == M.proj_bytes(c, M.primeorder_mul_ref(c, p, k)), i
+    out = cv.mul_by_generator(fe_arr(c, sc), out_format=ecgpu.PROJECTIVE, flags=ecgpu.EXACT_REFERENCE)
+    for i, k in enumerate(sc):
+        assert bytes(out[i]) == M.proj_bytes(c, M.primeorder_mul_ref(c, c.G, k)), i
+    # lincomb(x, k, y, l) = x*k + y*l  (primeorder/src/projective.rs:415-420)
+    n = 8
+    lp = rand_proj(c, rng, 2 * n, 4000)
+    lk = [rng.randrange(c.n) for _ in range(2 * n)]
+    out = cv.lincomb(fe_arr(c, lk), arr([M.proj_bytes(c, p) for p in lp], 3 * nb), terms=2, point_format=ecgpu.PROJECTIVE,
+                     out_format=ecgpu.PROJECTIVE, flags=ecgpu.EXACT_REFERENCE)
+    for i in range(n):
+        want = M.lincomb_ref(c, [(lp[2 * i], lk[2 * i]), (lp[2 * i + 1], lk[2 * i + 1])])
+        assert bytes(out[i]) == M.proj_bytes(c, want)
+
+
+@pytest.mark.parametrize("cn,cid", [("p256", 1), ("p384", 2)])
+def test_larger_batch_against_c_oracle_and_synth(ctx, cn, cid):
+    """2^12 seeded units generated on the device, multiplied on the device, checked against the C oracle."""
+    import torch
+    c = M.CURVES[cn]
+    cv = ctx.curve(cn)
+    nb = c.nbytes
+    n, first = 4096, 777
+    d_s = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
+    d_p = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+    d_o = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+    d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_s, n, synth.SEED, first)
+    cv.synth_points_device(d_p, n, synth.SEED, first)
+    cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i)
+    ctx.synchronize()
+    s, p = d_s.cpu().numpy(), d_p.cpu().numpy()
+    assert bytes(s) == bytes(CO.synth_scalars(cid, n, synth.SEED, first))
+    assert bytes(p) == bytes(CO.synth_points(cid, n, synth.SEED, first))
+    want = CO.lincomb_batch(cid, s, p, threads=4)
+    got = np.concatenate([d_o.cpu().numpy(), d_i.cpu().numpy()[:, None]], axis=1)
+    assert bytes(got) == bytes(want)
+
+
+@pytest.mark.parametrize("cn", CURVES)
+def test_validate_and_decompress(ctx, cn):
+    c = M.CURVES[cn]
+    cv = ctx.curve(cn)
+    nb = c.nbytes
+    rng = random.Random(54)
+    top = 1 << (8 * nb)
+    sc = [0, 1, c.n - 1, c.n, c.n + 1, top - 1] + [rng.randrange(top) for _ in range(40)]
+    assert list(cv.validate_scalars(fe_arr(c, sc))) == [1 if s < c.n else 0 for s in sc]
+    pts = [synth.point(c, i, seed=6) for i in range(16)]
+    bad = [(x, (y + 1) % c.p) for x, y in pts[:4]] + [(c.p, 1), (0, 0)]
+    allp = pts + bad
+    ok = cv.validate_points(arr([int(x).to_bytes(nb, "big") + int(y).to_bytes(nb, "big") for x, y in allp], 2 * nb))
+    assert list(ok) == [1] * 16 + [0] * 5 + [1]
+    xs = [p[0] for p in pts] + [rng.randrange(c.p) for _ in range(30)] + [c.p]
+    odd = [p[1] & 1 for p in pts] + [rng.randrange(2) for _ in range(31)]
+    out, okd = cv.decompress(fe_arr(c, xs), np.array(odd, dtype=np.uint8))
+    for i, (x, o) in enumerate(zip(xs, odd)):
+        want = M.decompress(c, x, o)
+        if want is None:
+            assert okd[i] == 0 and not out[i].any()
+        else:
+            assert okd[i] == 1 and bytes(out[i]) == M.i2b(c, want[0]) + M.i2b(c, want[1])
