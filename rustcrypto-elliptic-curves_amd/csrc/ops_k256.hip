@@ -1,5 +1,6 @@
 // secp256k1 kernels and launchers (one translation unit per curve: the library builds in parallel).
 #include "curve_ops.hpp"
+#include "msm_kernels.hpp"
 using namespace ecgpu;
 
 template <>
@@ -15,8 +16,47 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
   HIPCHK(c, hipGetLastError());
   return 1;
 }
+// Pippenger MSM (msm_k256.hpp).  All stages run on c->stream out of one grow-only workspace.
 template <>
-int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32*, const u32*, int, size_t, u32*, int) {
-  return ecgpu_set_err(c, ECGPU_ERR_UNSUPPORTED, "ecgpu_msm: not built yet");
+int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt) {
+  using namespace msm;
+  if (n >= (size_t)1 << 31) return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_msm: at most 2^31 - 1 terms per call");
+  const size_t nb = (size_t)NWIN * NBUCKET;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t sz_aff = (pt_fmt == FMT_PROJECTIVE) ? al(n * 64) : 0;
+  const size_t sz_digits = al((size_t)NWIN * n * 2), sz_hist = al((nb + 1) * 4), sz_sorted = al((size_t)NWIN * n * 4 + 4);
+  const size_t sz_buckets = al(nb * sizeof(JacK256)), sz_seg = al((size_t)NWIN * NSEG * sizeof(JacK256)), sz_win = al(NWIN * sizeof(JacK256));
+  const size_t need = sz_aff + sz_digits + 3 * sz_hist + sz_sorted + sz_buckets + 2 * sz_seg + sz_win;
+  if (need > c->msm_ws_cap) {
+    if (c->msm_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->msm_ws)); c->msm_ws = nullptr; c->msm_ws_cap = 0; }
+    HIPCHK(c, hipMalloc(&c->msm_ws, need));
+    c->msm_ws_cap = need;
+  }
+  char* p = (char*)c->msm_ws;
+  u32* aff = (u32*)p; p += sz_aff;
+  int16_t* digits = (int16_t*)p; p += sz_digits;
+  u32* hist = (u32*)p; p += sz_hist;
+  u32* offsets = (u32*)p; p += sz_hist;
+  u32* cursor = (u32*)p; p += sz_hist;
+  u32* sorted = (u32*)p; p += sz_sorted;
+  JacK256* buckets = (JacK256*)p; p += sz_buckets;
+  JacK256* seg_t = (JacK256*)p; p += sz_seg;
+  JacK256* seg_w = (JacK256*)p; p += sz_seg;
+  JacK256* win = (JacK256*)p;
+  const u32* xy = pts;
+  if (pt_fmt == FMT_PROJECTIVE) {
+    hipLaunchKernelGGL(to_affine_kernel, dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, pts, aff, n);
+    xy = aff;
+  }
+  HIPCHK(c, hipMemsetAsync(hist, 0, (nb + 1) * 4, c->stream));
+  if (n) hipLaunchKernelGGL(digits_hist_kernel, dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, sc, xy, n, digits, hist);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, c->stream, hist, offsets, cursor, (int)nb);
+  if (n) hipLaunchKernelGGL(scatter_kernel, dim3(ecgpu_grid_for(c, (size_t)NWIN * n, 8)), dim3(256), 0, c->stream, digits, n, cursor, sorted);
+  hipLaunchKernelGGL(bucket_sum_kernel, dim3(ecgpu_grid_for(c, nb, 16)), dim3(256), 0, c->stream, xy, offsets, sorted, buckets, (int)nb);
+  hipLaunchKernelGGL(segment_kernel, dim3((NWIN * NSEG + 63) / 64), dim3(64), 0, c->stream, buckets, seg_t, seg_w);
+  hipLaunchKernelGGL(window_kernel, dim3(1), dim3(64), 0, c->stream, seg_t, seg_w, win);
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, c->stream, win, out, out_fmt);
+  HIPCHK(c, hipGetLastError());
+  return 0;
 }
 const ecgpu_curve_ops* ecgpu_ops_k256() { return CurveOps<CurveK256>::table(); }

@@ -140,3 +140,16 @@ int ht_k256_jac_double(const uint8_t* p, uint8_t* out, int n) {
   return 0;
 }
 }
+
+// ---- MSM primitive: general Jacobian addition with exceptional cases ------------------------------
+#include "msm_k256.hpp"
+extern "C" int ht_k256_jac_add(const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
+  for (int i = 0; i < n; i++) {
+    JacK256 a, b, r;
+    load(a.x, p + 96 * i); load(a.y, p + 96 * i + 32); load(a.z, p + 96 * i + 64);
+    load(b.x, q + 96 * i); load(b.y, q + 96 * i + 32); load(b.z, q + 96 * i + 64);
+    msm::jac_add(r, a, b);
+    store(out + 96 * i, r.x); store(out + 96 * i + 32, r.y); store(out + 96 * i + 64, r.z);
+  }
+  return 0;
+}

@@ -1,0 +1,104 @@
+"""k256 multi-scalar multiplication (Pippenger) through the C ABI against the oracle."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import coracle as CO
+from oracle import ecmodel as M
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+C = M.K256
+N = C.n
+
+
+@pytest.fixture(scope="module")
+def curve():
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    yield ctx.curve("k256")
+    ctx.close()
+
+
+def arr(rows, w):
+    return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(-1, w).copy()
+
+
+def oracle_msm(ks, pts):
+    tot = None
+    for k, p in zip(ks, pts):
+        tot = M.affine_add(C, tot, M.affine_mul(C, k, p))
+    return tot
+
+
+def test_small_and_edge_cases(curve):
+    rng = random.Random(61)
+    G = (C.gx, C.gy)
+    cases = []
+    cases.append(([5], [G]))
+    cases.append(([0], [G]))
+    cases.append(([N - 1, 1], [G, G]))                          # sums to the identity
+    cases.append(([3, 3, 3], [G, G, G]))                        # duplicates: the doubling branch of the bucket sum
+    cases.append(([7, 9], [G, None]))                           # identity point among the inputs
+    cases.append(([2**16, 2**15, 2**15 - 1, 2**32 - 1, 2**255 % N], [synth.point(C, i, seed=61) for i in range(5)]))
+    ks = [rng.randrange(N) for _ in range(300)]
+    cases.append((ks, [synth.point(C, i, seed=62) for i in range(300)]))
+    for ks, pts in cases:
+        s = arr([M.i2b(C, k) for k in ks], 32)
+        p = arr([bytes(64) if q is None else M.i2b(C, q[0]) + M.i2b(C, q[1]) for q in pts], 64)
+        got = curve.msm(s, p)
+        want = oracle_msm(ks, pts)
+        assert bytes(got) == (bytes(64) if want is None else M.i2b(C, want[0]) + M.i2b(C, want[1])), ks[:3]
+
+
+def test_projective_io(curve):
+    import ecgpu
+    rng = random.Random(63)
+    n = 50
+    ks = [rng.randrange(N) for _ in range(n)]
+    pts = [synth.point(C, i, seed=63) for i in range(n)]
+    proj = []
+    for x, y in pts:
+        z = rng.randrange(1, C.p)
+        proj.append((x * z % C.p, y * z % C.p, z))
+    got = curve.msm(arr([M.i2b(C, k) for k in ks], 32), arr([M.proj_bytes(C, q) for q in proj], 96),
+                    point_format=ecgpu.PROJECTIVE, out_format=ecgpu.PROJECTIVE)
+    want = oracle_msm(ks, pts)
+    assert bytes(got) == M.i2b(C, want[0]) + M.i2b(C, want[1]) + M.i2b(C, 1)
+
+
+@pytest.mark.parametrize("lg", [10, 16])
+def test_unstructured_against_c_oracle(curve, lg):
+    """exact comparison against the CPU MSM at 2^10 and 2^16 unstructured terms."""
+    n = 1 << lg
+    s = CO.synth_scalars(0, n, synth.SEED, 5)
+    p = CO.synth_points(0, n, synth.SEED, 5)
+    want = CO.msm_naive(0, s, p)
+    got = curve.msm(s, p)
+    assert bytes(got) == bytes(want[:64]) and want[64] == 0
+
+
+def test_structured_large(curve):
+    """2^20 terms with P_i = (a0 + i d) G, so the answer is (sum k_i (a0 + i d) mod n) G."""
+    import torch
+    n = 1 << 20
+    a0, d = 0x1234567890ABCDEF1234567890ABCDEF % N, 0xFEDCBA0987654321 % N
+    ctx = curve.ctx
+    ks = CO.synth_scalars(0, n, synth.SEED, 0)
+    # point scalars a0 + i*d as big-endian bytes
+    vals = [(a0 + i * d) % N for i in range(n)]
+    ps = np.frombuffer(b"".join(v.to_bytes(32, "big") for v in vals), dtype=np.uint8).reshape(n, 32).copy()
+    d_ps = torch.from_numpy(ps).cuda()
+    d_pts = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    curve.mul_device(d_ps, None, d_pts, n)                       # P_i = (a0 + i d) G on the device
+    d_ks = torch.from_numpy(ks).cuda()
+    d_out = torch.empty((64,), dtype=torch.uint8, device="cuda")
+    curve.msm_device(d_ks, d_pts, n, d_out)
+    ctx.synchronize()
+    tot = 0
+    kb = ks.tobytes()
+    for i in range(n):
+        tot = (tot + int.from_bytes(kb[32 * i:32 * i + 32], "big") * vals[i]) % N
+    want = M.affine_mul(C, tot, (C.gx, C.gy))
+    assert bytes(d_out.cpu().numpy()) == M.i2b(C, want[0]) + M.i2b(C, want[1])

@@ -104,3 +104,25 @@ def test_mul_fast_group_vectors_and_config1(ref_vectors):
     got = run_fast(b"".join(bytes.fromhex(r[1] + r[2]) for r in rows), 0, [int(r[0], 16) for r in rows], 16)
     for i, r in enumerate(rows):
         assert got[i].hex() == r[3]
+
+
+def test_general_jacobian_add_with_exceptional_cases():
+    rng = random.Random(35)
+
+    def jac(A):
+        if A is None:
+            return (rng.randrange(P), rng.randrange(P), 0)
+        z = rng.randrange(1, P)
+        return (A[0] * z * z % P, A[1] * z * z * z % P, z)
+
+    pts = [synth.point(C, i, seed=35) for i in range(30)]
+    cases = [(pts[i], pts[i + 1]) for i in range(0, 28, 2)]
+    cases += [(pts[0], pts[0]), (pts[1], M.affine_neg(C, pts[1])), (None, pts[2]), (pts[3], None), (None, None)]
+    pin = b"".join(b"".join(fe(v) for v in jac(a)) for a, _ in cases)
+    qin = b"".join(b"".join(fe(v) for v in jac(b)) for _, b in cases)
+    out = outbuf(96 * len(cases))
+    assert lib().ht_k256_jac_add(buf(pin), buf(qin), out, len(cases)) == 0
+    o = bytes(out)
+    for i, (a, b) in enumerate(cases):
+        X, Y, Z = (int.from_bytes(o[96 * i + 32 * t:96 * i + 32 * t + 32], "big") for t in range(3))
+        assert jac_to_affine(X, Y, Z) == M.affine_add(C, a, b), i
