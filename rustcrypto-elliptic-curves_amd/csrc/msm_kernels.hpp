@@ -8,11 +8,23 @@ namespace msm {
 
 // 1. signed 16-bit digits + bucket histogram.  digits is window-major ([w][i]) so that the scatter
 //    pass reads it coalesced.  A term whose point is the identity contributes nothing.
-__global__ void __launch_bounds__(256) digits_hist_kernel(const u32* scalars, const u32* points_xy, size_t n, int16_t* digits, u32* hist) {
+__global__ void __launch_bounds__(256) digits_hist_kernel(const u32* scalars, const u32* points_xy, size_t n, int16_t* digits, uint8_t* flips,
+                                                          u32* hist) {
   ECGPU_GRID_STRIDE(i, n) {
     u32 k[8];
     words_load_be<8>(k, scalars + i * 8);
     k256::scalar_reduce_once(k);
+    // k > n/2: use (n - k, -P).  Then k < 2^255 and the carry window of the signed recoding is (almost
+    // always) empty; without this half of all terms land in its single bucket and one lane sums them.
+    bool flip;
+    {
+      u32 nn[8], t[8];
+      k256::order(nn);
+      mp_sub<8>(t, nn, k);                 // n - k
+      flip = !mp_geq<8>(t, k);             // n - k < k
+#pragma unroll
+      for (int w = 0; w < 8; w++) k[w] = flip ? t[w] : k[w];
+    }
     u32 z = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) z |= points_xy[i * 16 + w];
@@ -22,12 +34,13 @@ __global__ void __launch_bounds__(256) digits_hist_kernel(const u32* scalars, co
     for (int w = 0; w < 16; w++) {
       u32 d = ((k[w >> 1] >> (16 * (w & 1))) & 0xFFFFu) + carry;
       carry = (d >= 0x8000u) ? 1u : 0u;      // d in [2^15, 2^16] becomes d - 2^16 with a carry
-      int sd = (int)d - (int)(carry << 16);
+      int sd = (int)d - (int)(carry << 16);   // in [-2^15, 2^15): fits int16; the flip is applied by the scatter pass
       if (skip) sd = 0;
       digits[(size_t)w * n + i] = (int16_t)sd;
       if (sd != 0) atomicAdd(&hist[w * NBUCKET + (sd < 0 ? -sd : sd) - 1], 1u);
     }
     int top = skip ? 0 : (int)carry;
+    flips[i] = flip ? 1 : 0;
     digits[(size_t)16 * n + i] = (int16_t)top;
     if (top) atomicAdd(&hist[16 * NBUCKET + 0], 1u);
   }
@@ -55,7 +68,7 @@ __global__ void __launch_bounds__(1024) scan_kernel(const u32* hist, u32* offset
 }
 
 // 3. scatter the (term, sign) pairs into their buckets
-__global__ void __launch_bounds__(256) scatter_kernel(const int16_t* digits, size_t n, u32* cursor, u32* sorted) {
+__global__ void __launch_bounds__(256) scatter_kernel(const int16_t* digits, const uint8_t* flips, size_t n, u32* cursor, u32* sorted) {
   const size_t total = (size_t)NWIN * n;
   ECGPU_GRID_STRIDE(e, total) {
     const int w = (int)(e / n);
@@ -63,7 +76,8 @@ __global__ void __launch_bounds__(256) scatter_kernel(const int16_t* digits, siz
     const int sd = digits[e];
     if (sd != 0) {
       const u32 pos = atomicAdd(&cursor[w * NBUCKET + (sd < 0 ? -sd : sd) - 1], 1u);
-      sorted[pos] = (u32)i | (sd < 0 ? 0x80000000u : 0u);
+      const bool negate = (sd < 0) != (flips[i] != 0);
+      sorted[pos] = (u32)i | (negate ? 0x80000000u : 0u);
     }
   }
 }

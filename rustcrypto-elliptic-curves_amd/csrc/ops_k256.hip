@@ -24,9 +24,9 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   const size_t nb = (size_t)NWIN * NBUCKET;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t sz_aff = (pt_fmt == FMT_PROJECTIVE) ? al(n * 64) : 0;
-  const size_t sz_digits = al((size_t)NWIN * n * 2), sz_hist = al((nb + 1) * 4), sz_sorted = al((size_t)NWIN * n * 4 + 4);
+  const size_t sz_flips = al(n), sz_digits = al((size_t)NWIN * n * 2), sz_hist = al((nb + 1) * 4), sz_sorted = al((size_t)NWIN * n * 4 + 4);
   const size_t sz_buckets = al(nb * sizeof(JacK256)), sz_seg = al((size_t)NWIN * NSEG * sizeof(JacK256)), sz_win = al(NWIN * sizeof(JacK256));
-  const size_t need = sz_aff + sz_digits + 3 * sz_hist + sz_sorted + sz_buckets + 2 * sz_seg + sz_win;
+  const size_t need = sz_aff + sz_flips + sz_digits + 3 * sz_hist + sz_sorted + sz_buckets + 2 * sz_seg + sz_win;
   if (need > c->msm_ws_cap) {
     if (c->msm_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->msm_ws)); c->msm_ws = nullptr; c->msm_ws_cap = 0; }
     HIPCHK(c, hipMalloc(&c->msm_ws, need));
@@ -34,6 +34,7 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   }
   char* p = (char*)c->msm_ws;
   u32* aff = (u32*)p; p += sz_aff;
+  uint8_t* flips = (uint8_t*)p; p += sz_flips;
   int16_t* digits = (int16_t*)p; p += sz_digits;
   u32* hist = (u32*)p; p += sz_hist;
   u32* offsets = (u32*)p; p += sz_hist;
@@ -49,9 +50,9 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
     xy = aff;
   }
   HIPCHK(c, hipMemsetAsync(hist, 0, (nb + 1) * 4, c->stream));
-  if (n) hipLaunchKernelGGL(digits_hist_kernel, dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, sc, xy, n, digits, hist);
+  if (n) hipLaunchKernelGGL(digits_hist_kernel, dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, sc, xy, n, digits, flips, hist);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, c->stream, hist, offsets, cursor, (int)nb);
-  if (n) hipLaunchKernelGGL(scatter_kernel, dim3(ecgpu_grid_for(c, (size_t)NWIN * n, 8)), dim3(256), 0, c->stream, digits, n, cursor, sorted);
+  if (n) hipLaunchKernelGGL(scatter_kernel, dim3(ecgpu_grid_for(c, (size_t)NWIN * n, 8)), dim3(256), 0, c->stream, digits, flips, n, cursor, sorted);
   hipLaunchKernelGGL(bucket_sum_kernel, dim3(ecgpu_grid_for(c, nb, 16)), dim3(256), 0, c->stream, xy, offsets, sorted, buckets, (int)nb);
   hipLaunchKernelGGL(segment_kernel, dim3((NWIN * NSEG + 63) / 64), dim3(64), 0, c->stream, buckets, seg_t, seg_w);
   hipLaunchKernelGGL(window_kernel, dim3(1), dim3(64), 0, c->stream, seg_t, seg_w, win);

@@ -42,6 +42,9 @@ def test_small_and_edge_cases(curve):
     cases.append(([3, 3, 3], [G, G, G]))                        # duplicates: the doubling branch of the bucket sum
     cases.append(([7, 9], [G, None]))                           # identity point among the inputs
     cases.append(([2**16, 2**15, 2**15 - 1, 2**32 - 1, 2**255 % N], [synth.point(C, i, seed=61) for i in range(5)]))
+    edge = [(N - 1) // 2, (N + 1) // 2, N - 1, N - 2, (N - 2**255) % N, 2**255 - 1, 2**255 + 1, N - 2**16, N - 2**15, N - 32767,
+            0x7FFF8000 << 224, (0x7FFF << 240) | ((1 << 240) - 1)]
+    cases.append((edge, [synth.point(C, 50 + i, seed=61) for i in range(len(edge))]))
     ks = [rng.randrange(N) for _ in range(300)]
     cases.append((ks, [synth.point(C, i, seed=62) for i in range(300)]))
     for ks, pts in cases:

@@ -20,6 +20,15 @@ cv.synth_scalars_device(d_s, n, synth.SEED)
 if mode == "var":
     cv.synth_points_device(d_p, n, synth.SEED)
 ctx.synchronize()
+if mode == "msm":
+    cv.synth_points_device(d_p, n, synth.SEED); ctx.synchronize()
+    d_r = torch.empty((64,), dtype=torch.uint8, device="cuda")
+    for rep in range(4):
+        ctx.timer_start()
+        cv.msm_device(d_s, d_p, n, d_r)
+        ms = ctx.timer_stop()
+        print(f"{cn} msm: n=2^{lg} {ms:.2f} ms  {n/ms*1e3/1e6:.2f} M points/s", flush=True)
+    sys.exit(0)
 for rep in range(3):
     ctx.timer_start()
     cv.mul_device(d_s, d_p if mode == "var" else None, d_o, n, d_out_inf=d_i, flags=flags)
