@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include "ecgpu_internal.hpp"
 #include "kernels.hpp"
+#include "fixedbase.hpp"
 
 namespace ecgpu {
 
@@ -43,6 +44,29 @@ struct CurveOps {
     HIPCHK(c, hipGetLastError());
     c->gen_table[C::ID] = t;
     return 0;
+  }
+  // fixed-base table T[j][d-1] = d 2^(8j) G (fixedbase.hpp), built once per context
+  static int ensure_fb_table(ecgpu_ctx* c) {
+    if (c->fb_table[C::ID]) return 0;
+    const int total = fb::nwin<C>() * fb::ENTRIES;
+    void *tmp = nullptr, *tab = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, sizeof(Jac<C>) * total));
+    HIPCHK(c, hipMalloc(&tab, sizeof(AffEntry<C>) * total));
+    hipLaunchKernelGGL((fb::table_jac_kernel<C>), dim3((fb::nwin<C>() + 63) / 64), dim3(64), 0, c->stream, (Jac<C>*)tmp);
+    hipLaunchKernelGGL((fb::table_affine_kernel<C>), dim3((total + 255) / 256), dim3(256), 0, c->stream, (const Jac<C>*)tmp, (AffEntry<C>*)tab, total);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(tmp));
+    c->fb_table[C::ID] = tab;
+    return 0;
+  }
+  static int mul_gen_fast(ecgpu_ctx* c, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
+    int rc = ensure_fb_table(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL((fb::mul_kernel<C, 16, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
+                       (const AffEntry<C>*)c->fb_table[C::ID], out, out_fmt, out_inf, n);
+    HIPCHK(c, hipGetLastError());
+    return 1;
   }
   // curve-specific throughput kernels hook in here (specialised in ops_*.hip); returns 1 if it launched
   static int lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt,

@@ -23,6 +23,8 @@ struct ecgpu_ctx {
   size_t stage_cap[6] = {0, 0, 0, 0, 0, 0};
   // precomputed generator tables, one per curve, built on first use
   void* gen_table[3] = {nullptr, nullptr, nullptr};
+  // fixed-base tables of the throughput schedule (fixedbase.hpp)
+  void* fb_table[3] = {nullptr, nullptr, nullptr};
   // MSM workspace (grow-only)
   void* msm_ws = nullptr;
   size_t msm_ws_cap = 0;

@@ -1,0 +1,157 @@
+// Jacobian-coordinate group law over the curve traits (x = X/Z^2, y = Y/Z^3, infinity <=> Z = 0),
+// used by the throughput schedules of every curve.  The reference works in homogeneous projective
+// coordinates with complete formulas (k256 projective.rs:96-274, primeorder point_arithmetic.rs:199-317);
+// these are the cheaper incomplete formulas with their exceptional cases handled explicitly, so the
+// group element that comes out is the same for every input.
+#pragma once
+#include "traits.hpp"
+
+namespace ecgpu {
+
+template <class C>
+struct Jac {
+  typename C::Fe x, y, z;
+};
+template <class C>
+struct AffEntry {   // affine table entry in the curve's internal field form (no infinity: tables never hold it)
+  typename C::Fe x, y;
+};
+
+namespace jac {
+
+template <class C> ECGPU_HD void set_infinity(Jac<C>& p) { C::fe_zero(p.x); C::fe_zero(p.y); C::fe_zero(p.z); }
+template <class C> ECGPU_HD void fe_dbl(typename C::Fe& r, const typename C::Fe& a) { C::fe_add(r, a, a); }
+
+// In-place doubling.  a = 0 (k256): 3M + 4S.  a = -3 (NIST): 3M + 5S (dbl-2001-b).
+template <class C>
+ECGPU_HD void dbl(Jac<C>& p) {
+  using Fe = typename C::Fe;
+  if constexpr (C::A_IS_ZERO) {
+    Fe a, b, t;
+    C::fe_sqr(a, p.x);
+    C::fe_sqr(b, p.y);
+    C::fe_mul(p.z, p.y, p.z); fe_dbl<C>(p.z, p.z);
+    C::fe_mul(p.y, p.x, b); fe_dbl<C>(p.y, p.y); fe_dbl<C>(p.y, p.y);      // D
+    C::fe_sqr(b, b);                                                        // C
+    fe_dbl<C>(t, a); C::fe_add(a, t, a);                                    // E
+    C::fe_sqr(t, a);
+    C::fe_sub(t, t, p.y); C::fe_sub(p.x, t, p.y);
+    C::fe_sub(p.y, p.y, p.x); C::fe_mul(p.y, a, p.y);
+    fe_dbl<C>(b, b); fe_dbl<C>(b, b); fe_dbl<C>(b, b);
+    C::fe_sub(p.y, p.y, b);
+  } else {
+    // delta = Z^2, gamma = Y^2, beta = X gamma, alpha = 3 (X - delta)(X + delta),
+    // X3 = alpha^2 - 8 beta, Z3 = (Y + Z)^2 - gamma - delta, Y3 = alpha (4 beta - X3) - 8 gamma^2
+    Fe delta, gamma, beta, alpha, t;
+    C::fe_sqr(delta, p.z);
+    C::fe_sqr(gamma, p.y);
+    C::fe_mul(beta, p.x, gamma);
+    C::fe_sub(t, p.x, delta); C::fe_add(alpha, p.x, delta); C::fe_mul(alpha, t, alpha);
+    fe_dbl<C>(t, alpha); C::fe_add(alpha, t, alpha);
+    C::fe_add(t, p.y, p.z); C::fe_sqr(t, t); C::fe_sub(t, t, gamma); C::fe_sub(p.z, t, delta);
+    fe_dbl<C>(beta, beta); fe_dbl<C>(beta, beta);                           // 4 beta
+    C::fe_sqr(t, alpha); C::fe_sub(t, t, beta); C::fe_sub(p.x, t, beta);    // X3
+    C::fe_sub(t, beta, p.x); C::fe_mul(t, alpha, t);
+    C::fe_sqr(gamma, gamma); fe_dbl<C>(gamma, gamma); fe_dbl<C>(gamma, gamma); fe_dbl<C>(gamma, gamma);
+    C::fe_sub(p.y, t, gamma);
+  }
+}
+
+// In-place p += (x2, y2), (x2, y2) affine and not the identity.  8M + 3S, independent of the curve
+// coefficients.  Special cases by control flow: p at infinity; same point (doubling); opposite points
+// (Z3 = Z1 * 0 = 0 falls out of the formula).
+template <class C>
+ECGPU_HD void add_mixed(Jac<C>& p, const typename C::Fe& x2, const typename C::Fe& y2) {
+  using Fe = typename C::Fe;
+  if (C::fe_is_zero(p.z)) {
+    p.x = x2; p.y = y2; C::fe_one(p.z);
+    return;
+  }
+  Fe h, r, t, u;
+  C::fe_sqr(t, p.z);
+  C::fe_mul(h, x2, t);
+  C::fe_mul(t, p.z, t); C::fe_mul(r, t, y2);
+  C::fe_sub(h, h, p.x);
+  C::fe_sub(r, r, p.y);
+  if (__builtin_expect(C::fe_is_zero(h), 0)) {
+    if (C::fe_is_zero(r)) {               // same point
+      p.x = x2; p.y = y2; C::fe_one(p.z);
+      dbl<C>(p);
+    } else {                              // opposite points
+      set_infinity<C>(p);
+    }
+    return;
+  }
+  C::fe_mul(p.z, p.z, h);
+  C::fe_sqr(t, h);
+  C::fe_mul(h, t, h);
+  C::fe_mul(t, p.x, t);
+  C::fe_sqr(u, r);
+  C::fe_sub(u, u, h); C::fe_sub(u, u, t); C::fe_sub(p.x, u, t);
+  C::fe_sub(t, t, p.x); C::fe_mul(t, r, t);
+  C::fe_mul(h, p.y, h);
+  C::fe_sub(p.y, t, h);
+}
+
+// general addition r = p + q (11M + 5S), all special cases handled
+template <class C>
+ECGPU_HD void add(Jac<C>& r, const Jac<C>& p, const Jac<C>& q) {
+  using Fe = typename C::Fe;
+  if (C::fe_is_zero(p.z)) { r = q; return; }
+  if (C::fe_is_zero(q.z)) { r = p; return; }
+  Fe z1z1, z2z2, u1, u2, s1, s2, h, rr, t;
+  C::fe_sqr(z1z1, p.z); C::fe_sqr(z2z2, q.z);
+  C::fe_mul(u1, p.x, z2z2); C::fe_mul(u2, q.x, z1z1);
+  C::fe_mul(t, q.z, z2z2); C::fe_mul(s1, p.y, t);
+  C::fe_mul(t, p.z, z1z1); C::fe_mul(s2, q.y, t);
+  C::fe_sub(h, u2, u1);
+  C::fe_sub(rr, s2, s1);
+  if (C::fe_is_zero(h)) {
+    if (C::fe_is_zero(rr)) { r = p; dbl<C>(r); return; }
+    set_infinity<C>(r);
+    return;
+  }
+  Fe hh, hhh, v;
+  C::fe_sqr(hh, h); C::fe_mul(hhh, hh, h); C::fe_mul(v, u1, hh);
+  Jac<C> o;
+  C::fe_sqr(t, rr); C::fe_sub(t, t, hhh); C::fe_sub(t, t, v); C::fe_sub(o.x, t, v);
+  C::fe_sub(t, v, o.x); C::fe_mul(t, rr, t);
+  C::fe_mul(s1, s1, hhh); C::fe_sub(o.y, t, s1);
+  C::fe_mul(t, p.z, q.z); C::fe_mul(o.z, t, h);
+  r = o;
+}
+
+// Montgomery's trick over the cnt results of one lane: out x, y in internal form (identity -> zeros),
+// inf flags.  `pre` is scratch for cnt field elements.
+template <class C>
+ECGPU_HD void batch_to_affine(typename C::Fe* ax, typename C::Fe* ay, u32* inf, const Jac<C>* pts, int cnt, typename C::Fe* pre) {
+  using Fe = typename C::Fe;
+  Fe acc; C::fe_one(acc);
+#pragma unroll 1
+  for (int i = 0; i < cnt; i++) {
+    pre[i] = acc;
+    Fe z = pts[i].z;
+    if (C::fe_is_zero(z)) C::fe_one(z);
+    C::fe_mul(acc, acc, z);
+  }
+  Fe ai;
+  C::fe_inv(ai, acc);
+#pragma unroll 1
+  for (int i = cnt - 1; i >= 0; i--) {
+    Fe z = pts[i].z;
+    const bool zr = C::fe_is_zero(z);
+    if (zr) C::fe_one(z);
+    Fe zi, t;
+    C::fe_mul(zi, ai, pre[i]);
+    C::fe_mul(ai, ai, z);
+    C::fe_sqr(t, zi);
+    C::fe_mul(ax[i], pts[i].x, t);
+    C::fe_mul(t, t, zi);
+    C::fe_mul(ay[i], pts[i].y, t);
+    if (zr) { C::fe_zero(ax[i]); C::fe_zero(ay[i]); }
+    inf[i] = zr ? 1u : 0u;
+  }
+}
+
+}  // namespace jac
+}  // namespace ecgpu

@@ -6,7 +6,8 @@ using namespace ecgpu;
 template <>
 int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt,
                                       uint8_t* out_inf, size_t n) {
-  if (terms != 1 || !pts) return 0;
+  if (terms != 1) return 0;
+  if (!pts) return mul_gen_fast(c, sc, out, out_fmt, out_inf, n);
   // ECGPU_K256_FAST_WAVES (2/3/4) picks the occupancy variant; default chosen from measurements (profiles/r01_kbench_variants.txt)
   static const int waves = [] { const char* e = getenv("ECGPU_K256_FAST_WAVES"); int w = e ? atoi(e) : 4; return (w < 3 || w > 4) ? 4 : w; }();
   if (waves == 3)

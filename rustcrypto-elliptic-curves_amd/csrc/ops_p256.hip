@@ -3,8 +3,9 @@
 using namespace ecgpu;
 
 template <>
-int CurveOps<CurveP256>::lincomb_fast(ecgpu_ctx*, const u32*, const u32*, int, size_t, u32*, int, uint8_t*, size_t) {
-  return 0;   // reference schedule only for now
+int CurveOps<CurveP256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pts, int, size_t terms, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
+  if (terms == 1 && !pts) return mul_gen_fast(c, sc, out, out_fmt, out_inf, n);
+  return 0;   // variable base: reference schedule
 }
 template <>
 int CurveOps<CurveP256>::msm(ecgpu_ctx* c, const u32*, const u32*, int, size_t, u32*, int) {

@@ -24,6 +24,7 @@ struct CurveK256 {
   static constexpr int NB = 32;          // bytes
   static constexpr int REF_TABLE_PTS = 16;   // per-term scratch of the reference-faithful mul
   static constexpr int GEN_TABLE_PTS = 33 * 8;
+  static constexpr bool A_IS_ZERO = true;       // y^2 = x^3 + 7
   using Fe = FeK256;
   using Pt = PtK256;
   using Af = AfK256;
@@ -80,6 +81,7 @@ struct CurveNist {
   static constexpr int NB = 4 * NW;
   static constexpr int REF_TABLE_PTS = 16;
   static constexpr int GEN_TABLE_PTS = 1;       // mul_by_generator is G * k (primeorder/src/projective.rs:422-431)
+  static constexpr bool A_IS_ZERO = false;      // a = -3
   using Mod = typename P::Mod;
   using Fe = FeMont<Mod>;
   using Pt = PtNist<P>;
