@@ -44,6 +44,30 @@ ECGPU_HD void fold_top(u32* r, u64 T) {
   r[2] = addc(r[2], 0u, c2);
 }
 
+// r += T * C for T < 2^40 (T*C is at most three words).  The carry out of word 2 is rare (~2^-26):
+// it takes a branch that ripples it and, if 2^256 is crossed, folds once more (the wrapped value is
+// then tiny, so that last fold cannot carry).
+ECGPU_HD void fold_top_fast(u32* r, u64 T) {
+  const u32 t0 = (u32)T, t1 = (u32)(T >> 32);
+  const u64 p = (u64)t0 * C_LO;                     // t0 * 977
+  const u32 s1 = (u32)(p >> 32) + t1 * C_LO;        // < 2^19
+  u32 ca = 0;
+  const u32 a1 = addc(s1, t0, ca);                  // + (T << 32)
+  const u32 a2 = t1 + ca;
+  u32 c = 0;
+  r[0] = addc(r[0], (u32)p, c);
+  r[1] = addc(r[1], a1, c);
+  r[2] = addc(r[2], a2, c);
+  if (__builtin_expect(c != 0, 0)) {
+#pragma unroll
+    for (int i = 3; i < 8; i++) r[i] = addc(r[i], 0u, c);
+    u32 c2 = 0;
+    r[0] = addc(r[0], c ? C_LO : 0u, c2);
+    r[1] = addc(r[1], c, c2);
+    r[2] = addc(r[2], 0u, c2);
+  }
+}
+
 // r = a * b mod p (weakly reduced).  field_5x52.rs:288-449 (mul_inner) is the reference.
 // Columns 8..14 of the schoolbook product are summed first (H), then columns 0..7 are summed
 // together with H*C, so the pseudo-Mersenne fold rides on the same 96-bit accumulator.
@@ -92,13 +116,8 @@ ECGPU_HD void mul_high_column(u32* h, Acc96& c, const u32* a, const u32* b) {
 }
 template <int K>
 ECGPU_HD void mul_low_column(u32* t, Acc96& c, const u32* a, const u32* b, const u32* h) {
-  if constexpr (K == 0) {
-    const u32 xa[1] = {h[0]}, xb[1] = {C_LO};
-    mac_product_column<8, K, 1>(c, a, b, xa, xb);
-  } else {
-    const u32 xa[2] = {h[K], h[K - 1]}, xb[2] = {C_LO, 1u};
-    mac_product_column<8, K, 2>(c, a, b, xa, xb);
-  }
+  const u32 xa[1] = {h[K]}, xb[1] = {C_LO};
+  mac_product_column<8, K, 1>(c, a, b, xa, xb);
   t[K] = acc_pop(c);
 }
 ECGPU_HD void mul(FeK256& r, const FeK256& a, const FeK256& b) {
@@ -114,33 +133,34 @@ ECGPU_HD void mul(FeK256& r, const FeK256& a, const FeK256& b) {
   mul_low_column<2>(t, c, a.v, b.v, h); mul_low_column<3>(t, c, a.v, b.v, h);
   mul_low_column<4>(t, c, a.v, b.v, h); mul_low_column<5>(t, c, a.v, b.v, h);
   mul_low_column<6>(t, c, a.v, b.v, h); mul_low_column<7>(t, c, a.v, b.v, h);
-  // overflow above 2^256: remaining accumulator plus the last shifted word of H
-  const u64 T = c.lo + h[7];
+  // H * 2^32 (the other half of H * C) is one carry chain; its top word joins the overflow above 2^256
+  u32 cy = 0;
+  r.v[0] = t[0];
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = t[i];
-  fold_top(r.v, T);
+  for (int i = 1; i < 8; i++) r.v[i] = addc(t[i], h[i - 1], cy);
+  const u64 T = c.lo + h[7] + cy;
+  fold_top_fast(r.v, T);
 }
 #endif
 
-// reduce a 16-word integer modulo p
+// reduce a 16-word integer modulo p: lo + hi * 977 + (hi << 32), then fold what spills over 2^256
 ECGPU_HD void reduce16(FeK256& r, const u32* w) {
-  Acc96 c{0, 0};
+  u32 u[8];
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {          // U = hi * 977: no carries needed, hi_k * 977 + carry < 2^43
+    acc = (u64)w[8 + k] * C_LO + (acc >> 32);
+    u[k] = (u32)acc;
+  }
+  u32 c1 = 0, c2 = 0;
   u32 t[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    if (k == 0) {
-      const u32 pa[2] = {w[0], w[8]}, pb[2] = {1u, C_LO};
-      mac_cols<2>(c, pa, pb);
-    } else {
-      const u32 pa[3] = {w[k], w[8 + k], w[8 + k - 1]}, pb[3] = {1u, C_LO, 1u};
-      mac_cols<3>(c, pa, pb);
-    }
-    t[k] = acc_pop(c);
-  }
-  const u64 T = c.lo + w[15];
+  for (int k = 0; k < 8; k++) t[k] = addc(w[k], u[k], c1);
+  r.v[0] = t[0];
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = t[i];
-  fold_top(r.v, T);
+  for (int k = 1; k < 8; k++) r.v[k] = addc(t[k], w[8 + k - 1], c2);
+  const u64 T = (acc >> 32) + c1 + c2 + w[15];
+  fold_top_fast(r.v, T);
 }
 
 // r = a^2 mod p
