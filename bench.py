@@ -47,6 +47,27 @@ MODMUL_PER_UNIT = {
 }
 MAC_PER_MODMUL = 64
 BYTES_PER_UNIT = 32 + 64 + 65          # scalar + affine point in, x||y||inf out
+
+# Other BASELINE.json configs, selectable with --workload (the driver's default run is configs[1]).
+#   modmul: field multiplications/squarings per unit of the schedule that runs
+#   mac   : 32x32 multiply-accumulates of one schoolbook product (64 for 256-bit, 144 for 384-bit)
+WORKLOADS = {
+    "k256_varbase":   dict(curve="k256", cid=0, log2n=24, fixed=False, msm=False, metric="k256 variable-base scalar-muls/sec", unit="scalar-muls/s",
+                           modmul=None, mac=64, bytes_per_unit=32 + 64 + 65, kernel=None,
+                           desc="k256 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
+    "p256_fixedbase": dict(curve="p256", cid=1, log2n=24, fixed=True, msm=False, metric="p256 fixed-base (mul_by_generator) scalar-muls/sec", unit="scalar-muls/s",
+                           # 33 signed 8-bit windows: ~32.9 mixed additions (8M+3S) + batched normalise 6M+1S + (256S+128M)/16
+                           modmul=33 * 11 + 7 + 24, mac=64, bytes_per_unit=32 + 65, kernel="fb::mul_kernel<CurveP256,16,4>",
+                           desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
+    "p384_varbase":   dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
+                           # 96 windows x (4 doublings (3M+5S) + 15/16 general additions (11M+5S)) + table (4 dbl + 3 add) + normalise
+                           modmul=96 * (32 + 15) + 80 + 7 + 72, mac=144, bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,2>",
+                           desc="p384 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
+    "k256_msm":       dict(curve="k256", cid=0, log2n=23, fixed=False, msm=True, metric="k256 MSM points/sec", unit="points/s",
+                           # 16 signed 16-bit windows: one mixed addition (8M+3S) per term per window; bucket reduction amortised
+                           modmul=16 * 11, mac=64, bytes_per_unit=32 + 64, kernel="msm::bucket_sum_kernel (+ digits/scan/scatter/reduce)",
+                           desc="k256 multi-scalar multiplication, 2^%d terms per GPU (one sum; ranks exchange one point each), affine output"),
+}
 # v_mad_u64_u32 issues at half the FP32-FMA rate on gfx950 (measured, tools/ubench/valu_rates.hip):
 # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz
 PEAK_TMACS = 256 * 4 * 16 * 2.4e9 / 1e12
@@ -55,21 +76,25 @@ PEAK_HBM_GBS = 8000.0
 
 def cpu_baseline_worker(args):
     """Runs in a forked child BEFORE the parent touches the GPU: C oracle on a slice."""
-    first, n = args
+    first, n, cid, fixed, msm = args
     from oracle import coracle as CO
-    s = CO.synth_scalars(0, n, SEED, first)
-    p = CO.synth_points(0, n, SEED, first)
+    s = CO.synth_scalars(cid, n, SEED, first)
+    p = None if fixed else CO.synth_points(cid, n, SEED, first)
     t0 = time.perf_counter()
-    out = CO.lincomb_batch(0, s, p, threads=1)
+    if msm:
+        # the reference has no Pippenger: its large-N form is one reference multiplication per term plus an addition
+        out = CO.lincomb_batch(cid, s, p, out_proj=True, threads=1)
+    else:
+        out = CO.lincomb_batch(cid, s, p, threads=1)
     dt = time.perf_counter() - t0
     return first, n, dt, out.tobytes()
 
 
-def run_cpu_baseline(sample, procs):
+def run_cpu_baseline(sample, procs, cid=0, fixed=False, msm=False):
     """Reference CPU path (C port) on `sample` units spread over `procs` single-threaded processes."""
     from concurrent.futures import ProcessPoolExecutor
     per = (sample + procs - 1) // procs
-    jobs = [(i * per, min(per, sample - i * per)) for i in range(procs) if i * per < sample]
+    jobs = [(i * per, min(per, sample - i * per), cid, fixed, msm) for i in range(procs) if i * per < sample]
     t0 = time.perf_counter()
     with ProcessPoolExecutor(max_workers=procs) as ex:
         res = list(ex.map(cpu_baseline_worker, jobs))
@@ -84,7 +109,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log2n", type=int, default=24, help="units per GPU per step (BASELINE config: 2^24)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="k256_varbase",
+                    help="BASELINE.json config to run (default: configs[1], the headline metric)")
+    ap.add_argument("--log2n", type=int, default=0, help="units per GPU per step (0 = the config's size)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="units for the CPU baseline (0 = auto, about 10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schedule", choices=["fast", "ref"], default="fast",
@@ -94,6 +121,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    wl = WORKLOADS[args.workload]
+    if not args.log2n:
+        args.log2n = wl["log2n"]
     n = 1 << args.log2n
 
     # ---- CPU baseline first (rank 0, N = 1 only), before this process initialises the GPU ----------
@@ -102,8 +132,9 @@ def main():
         procs = max(1, min(os.cpu_count() or 1, 16))
         # the C port runs ~16 k units/s/core: 64 k units per process is ~4 s of work each (about a minute of CPU
         # time on 16 cores); --cpu-sample overrides
-        sample = args.cpu_sample or min(n, 65536 * procs)
-        cpu = run_cpu_baseline(sample, procs)
+        per_proc = {"k256": 65536, "p256": 8192, "p384": 4096}[wl["curve"]] // (1 if not wl["fixed"] or wl["curve"] != "k256" else 1)
+        sample = args.cpu_sample or min(n, per_proc * procs)
+        cpu = run_cpu_baseline(sample, procs, wl["cid"], wl["fixed"], wl["msm"])
         cpu["sample"] = sample
 
     import numpy as np
@@ -121,22 +152,41 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     ctx = ecgpu.Context(local_rank)
-    cv = ctx.curve("k256")
+    cv = ctx.curve(wl["curve"])
+    nb = cv.nb
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
     dev = torch.device("cuda", local_rank)
-    d_s = torch.empty((n, 32), dtype=torch.uint8, device=dev)
-    d_p = torch.empty((n, 64), dtype=torch.uint8, device=dev)
-    d_o = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    d_s = torch.empty((n, nb), dtype=torch.uint8, device=dev)
+    d_p = None if wl["fixed"] else torch.empty((n, 2 * nb), dtype=torch.uint8, device=dev)
+    d_o = torch.empty((1 if wl["msm"] else n, 2 * nb), dtype=torch.uint8, device=dev)
     d_i = torch.empty((n,), dtype=torch.uint8, device=dev)
     first = rank * n                         # disjoint slices of one global batch
     cv.synth_scalars_device(d_s, n, SEED, first)
-    cv.synth_points_device(d_p, n, SEED, first)
+    if d_p is not None:
+        cv.synth_points_device(d_p, n, SEED, first)
     torch.cuda.synchronize()
+    msm_result = {}
 
     def step():
-        cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i, flags=(ecgpu.EXACT_REFERENCE if args.schedule == "ref" else 0))
+        if wl["msm"]:
+            if dist is None:
+                cv.msm_device(d_s, d_p, n, d_o)
+            else:
+                # every rank sums its slice; one projective point per rank is all-gathered and folded locally
+                from ecgpu import parallel
+                d_part = torch.empty((3 * nb,), dtype=torch.uint8, device=dev)
+
+                def local_msm(lo, hi):
+                    cv.msm_device(d_s, d_p, n, d_part, out_format=ecgpu.PROJECTIVE)
+                    ctx.synchronize()
+                    return d_part.cpu().numpy()
+
+                tot = parallel.msm_sharded(local_msm, lambda a, b: cv.add(a.reshape(1, -1), b.reshape(1, -1))[0], world * n)
+                msm_result["xyz"] = tot
+        else:
+            cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i, flags=(ecgpu.EXACT_REFERENCE if args.schedule == "ref" else 0))
 
     def barrier():
         if dist is not None:
@@ -162,8 +212,31 @@ def main():
     parity = None
     if cpu is not None:
         m = cpu["sample"]
-        got = torch.cat([d_o[:m], d_i[:m, None]], dim=1).cpu().numpy().tobytes()
-        parity = (got == cpu["out"])
+        if wl["msm"]:
+            # the oracle computed k_i * P_i for the first m terms (projective); fold them with the oracle's
+            # complete addition and compare with the GPU MSM over the same m terms
+            from oracle import coracle as CO
+            parts = np.frombuffer(cpu["out"], dtype=np.uint8).reshape(m, 3 * nb)
+            while parts.shape[0] > 1:
+                if parts.shape[0] % 2:
+                    parts = np.concatenate([parts, np.frombuffer(b"".join([bytes(nb), (1).to_bytes(nb, "big"), bytes(nb)]), dtype=np.uint8)[None, :]])
+                parts = CO.point_op(wl["cid"], 0, parts[0::2].copy(), parts[1::2].copy())
+            d_chk = torch.empty((3 * nb,), dtype=torch.uint8, device=dev)
+            cv.msm_device(d_s, d_p, m, d_chk, out_format=ecgpu.PROJECTIVE)
+            ctx.synchronize()
+            g = d_chk.cpu().numpy().reshape(1, -1)
+            # compare as group elements: normalise both through the library-independent route (x = X/Z)
+            from oracle import ecmodel as M
+            c_ = M.CURVES[wl["curve"]]
+
+            def aff(b):
+                X, Y, Z = (int.from_bytes(bytes(b[0][nb * t:nb * (t + 1)]), "big") for t in range(3))
+                return M.to_affine(c_, (X, Y, Z))
+
+            parity = aff(parts) == aff(g)
+        else:
+            got = torch.cat([d_o[:m], d_i[:m, None]], dim=1).cpu().numpy().tobytes()
+            parity = (got == cpu["out"])
         if not parity:
             raise SystemExit("PARITY FAILURE: GPU output differs from the CPU oracle on the sampled units")
 
@@ -171,10 +244,10 @@ def main():
         units = world * n * args.steps
         value = units / elapsed
         kernel_s = kernel_ms / 1e3 / args.steps            # average launch duration, HIP events
-        modmul = MODMUL_PER_UNIT["k256_varbase_" + args.schedule]
-        macs_per_launch = n * modmul * MAC_PER_MODMUL
+        modmul = wl["modmul"] or MODMUL_PER_UNIT["k256_varbase_" + args.schedule]
+        macs_per_launch = n * modmul * wl["mac"]
         achieved_tmacs = macs_per_launch / kernel_s / 1e12
-        alg_bytes = n * BYTES_PER_UNIT
+        alg_bytes = n * wl["bytes_per_unit"]
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
@@ -184,9 +257,9 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "k256 variable-base scalar-muls/sec",
+            "metric": wl["metric"],
             "value": value,
-            "unit": "scalar-muls/s",
+            "unit": wl["unit"],
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -196,22 +269,23 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "k256 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output" % args.log2n,
+            "config": {"workload": wl["desc"] % args.log2n,
                        "units_per_gpu_per_step": n, "parallelism": "independent batches, %d GPU(s), no collective" % world,
                        "schedule": ("reference-faithful (GLV + signed radix-16, RCB complete formulas, per-point inversion)" if args.schedule == "ref"
-                                    else "throughput (GLV + signed radix-16, Jacobian, common-Z table, batched inversion)")},
+                                    else "throughput (GLV + signed radix-16, Jacobian, common-Z table, batched inversion)")
+                       if args.workload == "k256_varbase" else "throughput schedule of this workload (DESIGN.md section 4)"},
             "roofline": {
                 "bound": "valu", "achieved": achieved_tmacs, "peak": PEAK_TMACS, "unit": "TMAC/s (32x32+64 v_mad_u64_u32)",
                 "frac": achieved_tmacs / PEAK_TMACS, "traffic": traffic,
-                "kernel": ("lincomb_ref_kernel<CurveK256,1>" if args.schedule == "ref" else "k256_mul_fast_kernel<16>"), "kernel_ms": kernel_s * 1e3,
-                "modmul_per_unit": modmul, "mac_per_unit": modmul * MAC_PER_MODMUL,
+                "kernel": wl["kernel"] or ("lincomb_ref_kernel<CurveK256,1>" if args.schedule == "ref" else "k256_mul_fast_kernel<16,4>"), "kernel_ms": kernel_s * 1e3,
+                "modmul_per_unit": modmul, "mac_per_unit": modmul * wl["mac"],
                 "hbm": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": alg_bytes / kernel_s / 1e9 / PEAK_HBM_GBS, "bytes_per_unit": BYTES_PER_UNIT},
             },
         }
         if cpu is not None:
             line["cpu_baseline"] = {
-                "value": cpu["sample"] / cpu["busy_s"], "unit": "scalar-muls/s", "cores": cpu["procs"], "kind": "port",
+                "value": cpu["sample"] / cpu["busy_s"], "unit": wl["unit"], "cores": cpu["procs"], "kind": "port",
                 "sample": "first %d units of the same seeded batch, C restatement of the reference path (oracle/ecoracle.c), %d single-threaded processes; GPU output of the sample verified byte-identical" % (cpu["sample"], cpu["procs"]),
                 "wall_s": cpu["wall_s"], "parity_ok": bool(parity),
             }

@@ -32,7 +32,7 @@ struct CurveOps {
     return 0;
   }
   static int normalize(ecgpu_ctx* c, const u32* p, u32* out_xy, uint8_t* out_inf, size_t n) {
-    hipLaunchKernelGGL((normalize_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, p, out_xy, out_inf, n);
+    hipLaunchKernelGGL((normalize_kernel<C, 16>), dim3(ecgpu_grid_for((const ecgpu_ctx*)c, (n + 15) / 16, 8)), dim3(256), 0, c->stream, p, out_xy, out_inf, n);
     HIPCHK(c, hipGetLastError());
     return 0;
   }

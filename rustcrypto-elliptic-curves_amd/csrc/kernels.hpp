@@ -111,12 +111,52 @@ __global__ void __launch_bounds__(256) point_op_kernel(const u32* p, const u32* 
   }
 }
 
-template <class C>
+// BatchNormalize (k256 projective.rs:325-379, primeorder projective.rs:346-413): homogeneous (X:Y:Z) ->
+// affine with Montgomery's trick.  Each lane walks BATCH elements (grid stride apart, so loads stay
+// coalesced across the wave), multiplies their Z together, inverts once and unwinds: 1 inversion +
+// ~5 multiplications per point instead of 1 inversion per point.  Identity inputs (Z = 0) give
+// x = y = 0, infinity = 1 without disturbing the batch (same dummy-value trick as the reference, :361-364).
+template <class C, int BATCH>
 __global__ void __launch_bounds__(256) normalize_kernel(const u32* p, u32* out_xy, uint8_t* out_inf, size_t n) {
-  ECGPU_GRID_STRIDE(i, n) {
-    typename C::Pt a;
-    load_point<C>(a, p + i * 3 * C::NW, FMT_PROJECTIVE);
-    store_affine_from_projective<C>(out_xy + i * 2 * C::NW, out_inf ? out_inf + i : nullptr, a);
+  using Fe = typename C::Fe;
+  constexpr int NW = C::NW;
+  Fe zs[BATCH], pre[BATCH];
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t base = tid; base < n; base += T * BATCH) {
+    int cnt = 0;
+    Fe acc; C::fe_one(acc);
+#pragma unroll 1
+    for (int b = 0; b < BATCH; b++) {
+      const size_t i = base + (size_t)b * T;
+      if (i >= n) break;
+      Fe z;
+      C::fe_load(z, p + i * 3 * NW + 2 * NW);
+      zs[b] = z;
+      pre[b] = acc;
+      if (C::fe_is_zero(z)) C::fe_one(z);
+      C::fe_mul(acc, acc, z);
+      cnt = b + 1;
+    }
+    Fe ai;
+    C::fe_inv(ai, acc);
+#pragma unroll 1
+    for (int b = cnt - 1; b >= 0; b--) {
+      const size_t i = base + (size_t)b * T;
+      Fe z = zs[b], zi, x, y;
+      const bool zr = C::fe_is_zero(z);
+      if (zr) C::fe_one(z);
+      C::fe_mul(zi, ai, pre[b]);
+      C::fe_mul(ai, ai, z);
+      C::fe_load(x, p + i * 3 * NW);
+      C::fe_load(y, p + i * 3 * NW + NW);
+      C::fe_mul(x, x, zi);
+      C::fe_mul(y, y, zi);
+      if (zr) { C::fe_zero(x); C::fe_zero(y); }
+      C::fe_store(out_xy + i * 2 * NW, x);
+      C::fe_store(out_xy + i * 2 * NW + NW, y);
+      if (out_inf) out_inf[i] = zr ? 1 : 0;
+    }
   }
 }
 
