@@ -22,6 +22,11 @@ struct P256Mod {
   // R^2 mod p (field.rs:33-36), R mod p (field.rs:28-31)
   static constexpr u32 R2[8] = {0x00000003u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFBu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFDu, 0x00000004u};
   static constexpr u32 ONE[8] = {0x00000001u, 0x00000000u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFEu, 0x00000000u};
+  // p + 1 as a sum of word multiples: p = -1 + 2^96 + 2^192 + (2^32 - 1) 2^224.  The reduction adds m_i * p * 2^(32 i);
+  // the "-1" cancels the low word of column i (that is what defines m_i), the rest are these three terms.
+  static constexpr int NTERM = 3;
+  static constexpr int TERM_OFF[3] = {3, 6, 7};
+  static constexpr u32 TERM_MUL[3] = {1u, 1u, 0xFFFFFFFFu};
 };
 struct P384Mod {
   static constexpr int N = 12;
@@ -33,6 +38,10 @@ struct P384Mod {
                                  0x00000000u, 0x00000002u, 0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u};
   static constexpr u32 ONE[12] = {0x00000001u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0x00000001u, 0x00000000u,
                                   0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u};
+  // p = -1 + 2^32 + 2^96 (2^288 - 2^32 - 1): word 1 and the nine words 3..11
+  static constexpr int NTERM = 10;
+  static constexpr int TERM_OFF[10] = {1, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+  static constexpr u32 TERM_MUL[10] = {1u, 0xFFFFFFFFu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 };
 
 template <class M>
@@ -43,46 +52,46 @@ struct FeMont {
 
 namespace mont {
 
-// number of non-zero limbs p_j with j in [lo, hi]
+// number of reduction terms that land in column K: term (off, mul) of quotient digit m_i lands in column i + off
 template <class M>
-constexpr int nz_count(int lo, int hi) {
+constexpr int term_count(int K) {
   int c = 0;
-  for (int j = lo; j <= hi; j++) if (j >= 1 && j < M::N && M::P[j] != 0) c++;
+  for (int t = 0; t < M::NTERM; t++) {
+    const int i = K - M::TERM_OFF[t];
+    if (i >= 0 && i < M::N) c++;
+  }
   return c;
 }
 
 // One column of the finely integrated product scanning:
-//   c += sum_{i+j=K} a_i b_j  +  sum_{i+j=K, j>=1, p_j != 0} m_i p_j   (+ m_{K-1} for the p_0 = -1 term)
+//   c += sum_{i+j=K} a_i b_j  +  sum_{terms, i = K - off in [0, N)} m_i * mul
 template <class M, int K>
 ECGPU_HD void fips_column(Acc96& c, const u32* a, const u32* b, const u32* m) {
   constexpr int N = M::N;
   constexpr int LO = (K - (N - 1)) > 0 ? (K - (N - 1)) : 0;     // first i of the a*b products
   constexpr int HI = K < (N - 1) ? K : (N - 1);
-  constexpr int NPROD = HI - LO + 1;
-  // quotient digits available: m_0 .. m_{min(K-1, N-1)}; term m_i p_{K-i} needs 1 <= K-i <= N-1
-  constexpr int ILO = (K - (N - 1)) > 0 ? (K - (N - 1)) : 0;
-  constexpr int IHI = (K - 1) < (N - 1) ? (K - 1) : (N - 1);
-  constexpr int NRED = (IHI >= ILO) ? nz_count<M>(K - IHI, K - ILO) : 0;
-  constexpr int NCARRY = (K >= 1 && K <= N) ? 1 : 0;             // m_{K-1} * 2^32 from the p_0 = 2^32 - 1 term
-  constexpr int TOT = NPROD + NRED + NCARRY;
-  u32 pa[TOT > 0 ? TOT : 1], pb[TOT > 0 ? TOT : 1];
-  int n = 0;
+  constexpr int NPROD = (HI >= LO) ? HI - LO + 1 : 0;
+  constexpr int NRED = term_count<M>(K);
+  constexpr int TOT = NPROD + NRED;
+  if constexpr (TOT > 0) {
+    u32 pa[TOT], pb[TOT];
+    int n = 0;
 #pragma unroll
-  for (int i = LO; i <= HI; i++) { pa[n] = a[i]; pb[n] = b[K - i]; n++; }
+    for (int i = LO; i <= HI; i++) { pa[n] = a[i]; pb[n] = b[K - i]; n++; }
 #pragma unroll
-  for (int i = ILO; i <= IHI; i++) {
-    if (M::P[K - i] != 0) { pa[n] = m[i]; pb[n] = M::P[K - i]; n++; }
+    for (int t = 0; t < M::NTERM; t++) {
+      const int i = K - M::TERM_OFF[t];
+      if (i >= 0 && i < N) { pa[n] = m[i]; pb[n] = M::TERM_MUL[t]; n++; }
+    }
+    mac_cols<TOT>(c, pa, pb);
   }
-  if (NCARRY) { pa[n] = m[K - 1]; pb[n] = 1u; n++; }
-  mac_cols<TOT>(c, pa, pb);
 }
 
 template <class M, int K>
 ECGPU_HD void fips_low(Acc96& c, const u32* a, const u32* b, u32* m) {
   if constexpr (K < M::N) {
     fips_column<M, K>(c, a, b, m);
-    // m_K = low word; adding m_K * p_0 = m_K 2^32 - m_K clears it and carries m_K into the next
-    // column (done there as an (m_K, 1) product): popping the word is all that happens here
+    // m_K = low word of the column; the "-1" of p cancels it exactly, so popping it is all that happens here
     m[K] = acc_pop(c);
     fips_low<M, K + 1>(c, a, b, m);
   }
