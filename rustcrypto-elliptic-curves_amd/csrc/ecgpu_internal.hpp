@@ -25,6 +25,9 @@ struct ecgpu_ctx {
   void* gen_table[3] = {nullptr, nullptr, nullptr};
   // fixed-base tables of the throughput schedule (fixedbase.hpp)
   void* fb_table[3] = {nullptr, nullptr, nullptr};
+  // per-lane table workspace of the k256 variable-base kernel (grow-only)
+  void* tab_ws = nullptr;
+  size_t tab_ws_cap = 0;
   // MSM workspace (grow-only)
   void* msm_ws = nullptr;
   size_t msm_ws_cap = 0;

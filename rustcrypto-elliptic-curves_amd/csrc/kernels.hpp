@@ -199,7 +199,7 @@ struct K256FastPrep {
   FeK256 zfix;          // common table denominator times the input's own Z
 };
 
-__device__ __forceinline__ void k256_fast_prep(K256FastPrep* pp, TabEntryK256* tab, const u32* sc, const u32* src, int pt_fmt) {
+__device__ __forceinline__ void k256_fast_prep(K256FastPrep* pp, TabSlotK256* tab, const u32* sc, const u32* src, int pt_fmt) {
   u32 k[8];
   words_load_be<8>(k, sc);
   k256::scalar_reduce_once(k);
@@ -242,7 +242,7 @@ __device__ __forceinline__ void k256_fast_prep(K256FastPrep* pp, TabEntryK256* t
   k256::mul(pp->zfix, zg, pz);
 }
 
-__device__ __forceinline__ void k256_fast_loop(JacK256* out, const K256FastPrep* pp, const TabEntryK256* tab) {
+__device__ __forceinline__ void k256_fast_loop(JacK256* out, const K256FastPrep* pp, const TabSlotK256* tab) {
   u32 y1[4], y2[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) { y1[i] = pp->y1[i]; y2[i] = pp->y2[i]; }
@@ -311,8 +311,9 @@ __device__ __forceinline__ void k256_fast_finish(const JacK256* res, FeK256* pre
 
 template <int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k256_mul_fast_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out,
-                                                            int out_fmt, uint8_t* out_inf, size_t n) {
-  TabEntryK256 tab[8];
+                                                            int out_fmt, uint8_t* out_inf, size_t n, TabSlotK256* table_ws) {
+  // this lane's table: 16 slots x 64 B, contiguous, in the launch's global workspace (gridDim * 256 lanes)
+  TabSlotK256* tab = table_ws + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * K256_TAB_SLOTS;
   K256FastPrep prep;
   JacK256 res[BATCH];
   FeK256 pre[BATCH];

@@ -21,9 +21,15 @@ namespace ecgpu {
 struct JacK256 {   // x = X / Z^2, y = Y / Z^3, infinity <=> Z == 0
   FeK256 x, y, z;
 };
-struct TabEntryK256 {   // affine point on the isomorphic curve, with beta*x alongside
-  FeK256 x, bx, y;
+// Table slot: an affine point on the isomorphic curve, 64 contiguous bytes.  The table holds two slots per
+// multiple, [2(j-1)] = (x, y) and [2(j-1)+1] = (beta*x, y), so that either GLV half reads ONE 64-byte block
+// of the lane's own table (a lane-divergent read of lane-contiguous memory: no over-fetch; kept in a global
+// workspace rather than the dword-interleaved private segment, where a divergent index touches up to eight
+// 256-byte rows per dword).
+struct alignas(16) TabSlotK256 {
+  FeK256 x, y;
 };
+constexpr int K256_TAB_SLOTS = 16;
 
 namespace k256 {
 
@@ -92,9 +98,10 @@ ECGPU_HD void jac_add_mixed(JacK256& r, const JacK256& p, const FeK256& x2, cons
 }
 
 // [P, 2P, .., 8P] with a common denominator.  On return tab[j-1] = (x', beta x', y') are the affine
-// coordinates of jP on the curve isomorphic by u = `zglobal` (x' = x u^2, y' = y u^3), i.e. Jacobian
+// coordinates of jP (slots 2(j-1) and, with beta*x, 2(j-1)+1) on the curve isomorphic by u = `zglobal`
+// (x' = x u^2, y' = y u^3), i.e. Jacobian
 // coordinates (x', y', zglobal) of jP on secp256k1.  P must not be the identity.
-ECGPU_HD void table_build_globalz(TabEntryK256* tab, FeK256& zglobal, const FeK256& px, const FeK256& py) {
+ECGPU_HD void table_build_globalz(TabSlotK256* tab, FeK256& zglobal, const FeK256& px, const FeK256& py) {
   JacK256 m[8];       // m[j] = (j+1) P, Jacobian
   FeK256 zr[8];       // zr[j] = Z(m[j]) / Z(m[j-1]),  j >= 2
   m[0].x = px; m[0].y = py; set_one(m[0].z);
@@ -105,8 +112,8 @@ ECGPU_HD void table_build_globalz(TabEntryK256* tab, FeK256& zglobal, const FeK2
   FeK256 beta_; beta(beta_);
   // scale m[j] to the denominator of m[7]: s_j = Z7 / Z_j = prod_{i > j} zr[i]
   FeK256 s; set_one(s);
-  tab[7].x = m[7].x; tab[7].y = m[7].y;
-  mul(tab[7].bx, tab[7].x, beta_);
+  tab[14].x = m[7].x; tab[14].y = m[7].y; tab[15].y = m[7].y;
+  mul(tab[15].x, m[7].x, beta_);
 #pragma unroll 1
   for (int j = 6; j >= 0; j--) {
     if (j >= 1) mul(s, s, zr[j + 1]);        // s = Z7 / Z_j for j >= 1 (Z_1 = Z(m[1]))
@@ -114,18 +121,20 @@ ECGPU_HD void table_build_globalz(TabEntryK256* tab, FeK256& zglobal, const FeK2
     FeK256 s2, s3;
     sqr(s2, s);
     mul(s3, s2, s);
-    mul(tab[j].x, m[j].x, s2);
-    mul(tab[j].y, m[j].y, s3);
-    mul(tab[j].bx, tab[j].x, beta_);
+    FeK256 tx, ty;
+    mul(tx, m[j].x, s2);
+    mul(ty, m[j].y, s3);
+    tab[2 * j].x = tx; tab[2 * j].y = ty; tab[2 * j + 1].y = ty;
+    mul(tab[2 * j + 1].x, tx, beta_);
   }
 }
 
 // Adds digit d of one GLV half: d in [-8, 8], `lam` selects beta*x, `neg` is the sign of that half.
-ECGPU_HD void add_digit(JacK256& acc, const TabEntryK256* tab, int d, bool lam, bool neg) {
+ECGPU_HD void add_digit(JacK256& acc, const TabSlotK256* tab, int d, bool lam, bool neg) {
   const int ad = d < 0 ? -d : d;
   if (ad != 0) {
-    const TabEntryK256* e = tab + (ad - 1);
-    FeK256 x = lam ? e->bx : e->x;
+    const TabSlotK256* e = tab + (2 * (ad - 1) + (lam ? 1 : 0));
+    FeK256 x = e->x;
     FeK256 y = e->y;
     if (neg != (d < 0)) k256::neg(y, y);
     jac_add_mixed(acc, x, y, nullptr);
@@ -133,7 +142,7 @@ ECGPU_HD void add_digit(JacK256& acc, const TabEntryK256* tab, int d, bool lam, 
 }
 
 // k * P for an affine, non-identity P; result in Jacobian coordinates on secp256k1.
-ECGPU_HD void mul_fast_jac(JacK256& acc, const FeK256& px, const FeK256& py, const u32* k, TabEntryK256* tab) {
+ECGPU_HD void mul_fast_jac(JacK256& acc, const FeK256& px, const FeK256& py, const u32* k, TabSlotK256* tab) {
   GlvSplit s;
   glv_split(s, k);
   FeK256 zg;

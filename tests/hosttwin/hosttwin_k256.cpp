@@ -86,7 +86,7 @@ int ht_k256_to_affine(const uint8_t* pts, uint8_t* out, int n) {
 extern "C" {
 // points: affine x||y (zeros = identity) or, with proj != 0, homogeneous X||Y||Z; out: x||y||inf (65 B)
 int ht_k256_mul_fast(const uint8_t* pts, int proj, const uint8_t* ks, uint8_t* out, int n, int batch) {
-  TabEntryK256 tab[8];
+  TabSlotK256 tab[K256_TAB_SLOTS];
   JacK256* res = (JacK256*)malloc(sizeof(JacK256) * batch);
   FeK256* pre = (FeK256*)malloc(sizeof(FeK256) * batch * 3);
   u32* inf = (u32*)malloc(sizeof(u32) * batch);

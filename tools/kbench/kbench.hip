@@ -25,11 +25,12 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL((synth_scalars_kernel<CurveK256>), dim3(cus * 8), dim3(256), 0, 0, (u64)0xEC5CA1A5ull, (u64)0, ds, n);
   hipLaunchKernelGGL((synth_points_kernel<CurveK256>), dim3(cus * 8), dim3(256), 0, 0, (u64)0xEC5CA1A5ull, (u64)0, dp, n);
   CK(hipDeviceSynchronize());
+  TabSlotK256* ws; CK(hipMalloc(&ws, (size_t)cus * KB_WAVES * 256 * K256_TAB_SLOTS * sizeof(TabSlotK256)));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f;
   for (int r = 0; r < reps + 1; r++) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k256_mul_fast_kernel<KB_BATCH, KB_WAVES>), dim3(cus * KB_WAVES), dim3(256), 0, 0, ds, dp, 0, dout, 0, dinf, n);
+    hipLaunchKernelGGL((k256_mul_fast_kernel<KB_BATCH, KB_WAVES>), dim3(cus * KB_WAVES), dim3(256), 0, 0, ds, dp, 0, dout, 0, dinf, n, ws);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (r > 0 && ms < best) best = ms;
