@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--log2n", type=int, default=0, help="units per GPU per step (0 = the config's size)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="units for the CPU baseline (0 = auto, about 10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse several ranks on one GPU)")
     ap.add_argument("--schedule", choices=["fast", "ref"], default="fast",
                     help="fast = throughput schedule (affine result specified); ref = reference-faithful schedule (exact XYZ)")
     args = ap.parse_args()
@@ -143,13 +144,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        if args.backend == "nccl":
+            raise SystemExit("rank %d has no GPU of its own (%d visible): one process per GPU" % (local_rank, ndev))
+        local_rank %= ndev                  # gloo rehearsal: ranks share the card
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     ctx = ecgpu.Context(local_rank)
     cv = ctx.curve(wl["curve"])
@@ -204,7 +210,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
