@@ -276,7 +276,8 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": wl["desc"] % args.log2n,
-                       "units_per_gpu_per_step": n, "parallelism": "independent batches, %d GPU(s), no collective" % world,
+                       "units_per_gpu_per_step": n, "parallelism": (("one sum split over %d GPU(s): per-rank Pippenger, all-gather of one projective point per rank, local complete additions" % world)
+                                       if wl["msm"] else ("independent batches, %d GPU(s), no collective" % world)),
                        "schedule": ("reference-faithful (GLV + signed radix-16, RCB complete formulas, per-point inversion)" if args.schedule == "ref"
                                     else "throughput (GLV + signed radix-16, Jacobian, common-Z table, batched inversion)")
                        if args.workload == "k256_varbase" else "throughput schedule of this workload (DESIGN.md section 4)"},

@@ -6,43 +6,46 @@
 namespace ecgpu {
 namespace msm {
 
-// 1. signed 16-bit digits + bucket histogram.  digits is window-major ([w][i]) so that the scatter
-//    pass reads it coalesced.  A term whose point is the identity contributes nothing.
-__global__ void __launch_bounds__(256) digits_hist_kernel(const u32* scalars, const u32* points_xy, size_t n, int16_t* digits, uint8_t* flips,
-                                                          u32* hist) {
+// Signed 16-bit digits of one term (registers only).  k > n/2 is replaced by n - k with the opposite sign
+// (then k < 2^255 and the carry window of the recoding is almost always empty; without this half of all
+// terms land in its single bucket and one lane sums them).  d[w] in [-2^15, 2^15), d[16] in {0, 1};
+// returns the sign flip.  A term whose point is the identity gets all-zero digits.
+__device__ __forceinline__ bool term_digits(int* d, const u32* scalars, const u32* points_xy, size_t i) {
+  u32 k[8];
+  words_load_be<8>(k, scalars + i * 8);
+  k256::scalar_reduce_once(k);
+  bool flip;
+  {
+    u32 nn[8], t[8];
+    k256::order(nn);
+    mp_sub<8>(t, nn, k);                 // n - k
+    flip = !mp_geq<8>(t, k);             // n - k < k
+#pragma unroll
+    for (int w = 0; w < 8; w++) k[w] = flip ? t[w] : k[w];
+  }
+  u32 z = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) z |= points_xy[i * 16 + w];
+  const bool skip = (z == 0);
+  u32 carry = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) {
+    const u32 v = ((k[w >> 1] >> (16 * (w & 1))) & 0xFFFFu) + carry;
+    carry = (v >= 0x8000u) ? 1u : 0u;      // v in [2^15, 2^16] becomes v - 2^16 with a carry
+    d[w] = skip ? 0 : (int)v - (int)(carry << 16);
+  }
+  d[16] = skip ? 0 : (int)carry;
+  return flip;
+}
+
+// 1. bucket histogram (one lane per term, 17 atomics)
+__global__ void __launch_bounds__(256) hist_kernel(const u32* scalars, const u32* points_xy, size_t n, u32* hist) {
   ECGPU_GRID_STRIDE(i, n) {
-    u32 k[8];
-    words_load_be<8>(k, scalars + i * 8);
-    k256::scalar_reduce_once(k);
-    // k > n/2: use (n - k, -P).  Then k < 2^255 and the carry window of the signed recoding is (almost
-    // always) empty; without this half of all terms land in its single bucket and one lane sums them.
-    bool flip;
-    {
-      u32 nn[8], t[8];
-      k256::order(nn);
-      mp_sub<8>(t, nn, k);                 // n - k
-      flip = !mp_geq<8>(t, k);             // n - k < k
+    int d[NWIN];
+    (void)term_digits(d, scalars, points_xy, i);
 #pragma unroll
-      for (int w = 0; w < 8; w++) k[w] = flip ? t[w] : k[w];
-    }
-    u32 z = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) z |= points_xy[i * 16 + w];
-    const bool skip = (z == 0);
-    u32 carry = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) {
-      u32 d = ((k[w >> 1] >> (16 * (w & 1))) & 0xFFFFu) + carry;
-      carry = (d >= 0x8000u) ? 1u : 0u;      // d in [2^15, 2^16] becomes d - 2^16 with a carry
-      int sd = (int)d - (int)(carry << 16);   // in [-2^15, 2^15): fits int16; the flip is applied by the scatter pass
-      if (skip) sd = 0;
-      digits[(size_t)w * n + i] = (int16_t)sd;
-      if (sd != 0) atomicAdd(&hist[w * NBUCKET + (sd < 0 ? -sd : sd) - 1], 1u);
-    }
-    int top = skip ? 0 : (int)carry;
-    flips[i] = flip ? 1 : 0;
-    digits[(size_t)16 * n + i] = (int16_t)top;
-    if (top) atomicAdd(&hist[16 * NBUCKET + 0], 1u);
+    for (int w = 0; w < NWIN; w++)
+      if (d[w] != 0) atomicAdd(&hist[w * NBUCKET + (d[w] < 0 ? -d[w] : d[w]) - 1], 1u);
   }
 }
 
@@ -67,18 +70,22 @@ __global__ void __launch_bounds__(1024) scan_kernel(const u32* hist, u32* offset
   if (t == 1023) offsets[total] = part[1023];
 }
 
-// 3. scatter the (term, sign) pairs into their buckets
-__global__ void __launch_bounds__(256) scatter_kernel(const int16_t* digits, const uint8_t* flips, size_t n, u32* cursor, u32* sorted) {
-  const size_t total = (size_t)NWIN * n;
-  ECGPU_GRID_STRIDE(e, total) {
-    const int w = (int)(e / n);
-    const size_t i = e - (size_t)w * n;
-    const int sd = digits[e];
-    if (sd != 0) {
-      const u32 pos = atomicAdd(&cursor[w * NBUCKET + (sd < 0 ? -sd : sd) - 1], 1u);
-      const bool negate = (sd < 0) != (flips[i] != 0);
-      sorted[pos] = (u32)i | (negate ? 0x80000000u : 0u);
+// 3. scatter the (term, sign) pairs into their buckets (digits recomputed: cheaper than storing and
+//    re-reading 34 bytes per term)
+__global__ void __launch_bounds__(256) scatter_kernel(const u32* scalars, const u32* points_xy, size_t n, u32* cursor, u32* sorted) {
+  ECGPU_GRID_STRIDE(i, n) {
+    int d[NWIN];
+    const bool flip = term_digits(d, scalars, points_xy, i);
+    // all 17 returning atomics are issued before any result is used, so their latencies overlap
+    u32 pos[NWIN];
+#pragma unroll
+    for (int w = 0; w < NWIN; w++) {
+      const int a = d[w] < 0 ? -d[w] : d[w];
+      pos[w] = a ? atomicAdd(&cursor[w * NBUCKET + a - 1], 1u) : 0u;
     }
+#pragma unroll
+    for (int w = 0; w < NWIN; w++)
+      if (d[w] != 0) sorted[pos[w]] = (u32)i | (((d[w] < 0) != flip) ? 0x80000000u : 0u);
   }
 }
 
@@ -102,40 +109,67 @@ __global__ void __launch_bounds__(256, 4) bucket_sum_kernel(const u32* points_xy
   }
 }
 
-// 5. per (window, segment): T = sum_t B_t and Wt = sum_t t * B_t over SEG consecutive buckets
-__global__ void __launch_bounds__(64) segment_kernel(const JacK256* buckets, JacK256* seg_t, JacK256* seg_w) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;       // window * NSEG + segment
-  if (s >= NWIN * NSEG) return;
-  const JacK256* B = buckets + (size_t)s * SEG;
+// 5. Weighted sums by a tree of running sums.  For a run of L points B_0..B_{L-1},
+//      T = sum B_t   and   Wt = sum (t + 1) B_t
+//    come from 2L additions (run += B_t from the top, wt += run).  Level 0 does this for every SEG0
+//    consecutive buckets; level 1 for every SEG1 consecutive level-0 results; the window kernel
+//    finishes.  With weights nested as j + 1 = (s1 * SEG1 + s0) * SEG0 + t + 1:
+//      S = sum_j (j+1) B_j = sum Wt0 + SEG0 * [ sum_{s1} ( (Wt1 - T1) ) + SEG1 * sum_{s1} s1 * T1 ]
+//    where T1/Wt1 are the level-1 sums over the level-0 totals T0 (Wt1 weights them 1..SEG1).
+__global__ void __launch_bounds__(64) segment_kernel(const JacK256* in, JacK256* out_t, JacK256* out_w, int len, int total) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= total) return;
+  const JacK256* B = in + (size_t)s * len;
   JacK256 run, wt;
   k256::set_zero(run.x); k256::set_zero(run.y); k256::set_zero(run.z);
   wt = run;
 #pragma unroll 1
-  for (int t = SEG - 1; t >= 0; t--) {
+  for (int t = len - 1; t >= 0; t--) {
     jac_add(run, run, B[t]);
     jac_add(wt, wt, run);
   }
-  seg_t[s] = run;
-  seg_w[s] = wt;
+  out_t[s] = run;
+  out_w[s] = wt;
+}
+// plain sums of `len` consecutive points (for the sum of the level-0 weighted parts)
+__global__ void __launch_bounds__(64) sum_kernel(const JacK256* in, JacK256* out, int len, int total) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= total) return;
+  JacK256 acc;
+  k256::set_zero(acc.x); k256::set_zero(acc.y); k256::set_zero(acc.z);
+#pragma unroll 1
+  for (int t = 0; t < len; t++) jac_add(acc, acc, in[(size_t)s * len + t]);
+  out[s] = acc;
 }
 
-// 6. per window: S_w = sum_j j * B_j = SEG * sum_s s * T_s + sum_s Wt_s
-__global__ void __launch_bounds__(64) window_kernel(const JacK256* seg_t, const JacK256* seg_w, JacK256* win) {
+// 6. per window: combine NSEG1 level-1 results
+//      S_w = sumW0 + SEG0 * ( sum_{s1} (Wt1 - T1)  +  SEG1 * sum_{s1} s1 * T1 )
+__global__ void __launch_bounds__(64) window_kernel(const JacK256* t1, const JacK256* w1, const JacK256* sumw0, JacK256* win) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= NWIN) return;
-  JacK256 run, acc, sw;
+  JacK256 run, acc, inner, neg;
   k256::set_zero(run.x); k256::set_zero(run.y); k256::set_zero(run.z);
-  acc = run; sw = run;
+  acc = run; inner = run;
 #pragma unroll 1
-  for (int s = NSEG - 1; s >= 0; s--) {
-    jac_add(sw, sw, seg_w[w * NSEG + s]);
+  for (int s = NSEG1 - 1; s >= 0; s--) {
+    jac_add(inner, inner, w1[w * NSEG1 + s]);
+    neg = t1[w * NSEG1 + s];
+    k256::neg(neg.y, neg.y);
+    jac_add(inner, inner, neg);                    // Wt1 - T1
     if (s >= 1) {
-      jac_add(run, run, seg_t[w * NSEG + s]);
-      jac_add(acc, acc, run);
+      jac_add(run, run, t1[w * NSEG1 + s]);
+      jac_add(acc, acc, run);                      // sum s1 * T1
     }
   }
 #pragma unroll 1
-  for (int j = 0; j < 8; j++) k256::jac_double(acc);          // * SEG = 2^8
+  for (int j = 0; j < LOG_SEG1; j++) k256::jac_double(acc);
+  jac_add(acc, acc, inner);
+#pragma unroll 1
+  for (int j = 0; j < LOG_SEG0; j++) k256::jac_double(acc);
+  JacK256 sw;
+  k256::set_zero(sw.x); k256::set_zero(sw.y); k256::set_zero(sw.z);
+#pragma unroll 1
+  for (int g = 0; g < NSUMW; g++) jac_add(sw, sw, sumw0[w * NSUMW + g]);
   jac_add(acc, acc, sw);
   win[w] = acc;
 }

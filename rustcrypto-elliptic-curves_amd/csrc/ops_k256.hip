@@ -34,9 +34,11 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   const size_t nb = (size_t)NWIN * NBUCKET;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t sz_aff = (pt_fmt == FMT_PROJECTIVE) ? al(n * 64) : 0;
-  const size_t sz_flips = al(n), sz_digits = al((size_t)NWIN * n * 2), sz_hist = al((nb + 1) * 4), sz_sorted = al((size_t)NWIN * n * 4 + 4);
-  const size_t sz_buckets = al(nb * sizeof(JacK256)), sz_seg = al((size_t)NWIN * NSEG * sizeof(JacK256)), sz_win = al(NWIN * sizeof(JacK256));
-  const size_t need = sz_aff + sz_flips + sz_digits + 3 * sz_hist + sz_sorted + sz_buckets + 2 * sz_seg + sz_win;
+  const size_t sz_hist = al((nb + 1) * 4), sz_sorted = al((size_t)NWIN * n * 4 + 4);
+  const size_t sz_buckets = al(nb * sizeof(JacK256));
+  const size_t n0 = (size_t)NWIN * NSEG0, n1 = (size_t)NWIN * NSEG1, nsw = (size_t)NWIN * NSUMW;
+  const size_t sz_l0 = al(n0 * sizeof(JacK256)), sz_l1 = al(n1 * sizeof(JacK256)), sz_sw = al(nsw * sizeof(JacK256)), sz_win = al(NWIN * sizeof(JacK256));
+  const size_t need = sz_aff + 3 * sz_hist + sz_sorted + sz_buckets + 2 * sz_l0 + 2 * sz_l1 + sz_sw + sz_win;
   if (need > c->msm_ws_cap) {
     if (c->msm_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->msm_ws)); c->msm_ws = nullptr; c->msm_ws_cap = 0; }
     HIPCHK(c, hipMalloc(&c->msm_ws, need));
@@ -44,15 +46,16 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   }
   char* p = (char*)c->msm_ws;
   u32* aff = (u32*)p; p += sz_aff;
-  uint8_t* flips = (uint8_t*)p; p += sz_flips;
-  int16_t* digits = (int16_t*)p; p += sz_digits;
   u32* hist = (u32*)p; p += sz_hist;
   u32* offsets = (u32*)p; p += sz_hist;
   u32* cursor = (u32*)p; p += sz_hist;
   u32* sorted = (u32*)p; p += sz_sorted;
   JacK256* buckets = (JacK256*)p; p += sz_buckets;
-  JacK256* seg_t = (JacK256*)p; p += sz_seg;
-  JacK256* seg_w = (JacK256*)p; p += sz_seg;
+  JacK256* t0 = (JacK256*)p; p += sz_l0;
+  JacK256* w0 = (JacK256*)p; p += sz_l0;
+  JacK256* t1 = (JacK256*)p; p += sz_l1;
+  JacK256* w1 = (JacK256*)p; p += sz_l1;
+  JacK256* sumw0 = (JacK256*)p; p += sz_sw;
   JacK256* win = (JacK256*)p;
   const u32* xy = pts;
   if (pt_fmt == FMT_PROJECTIVE) {
@@ -60,12 +63,14 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
     xy = aff;
   }
   HIPCHK(c, hipMemsetAsync(hist, 0, (nb + 1) * 4, c->stream));
-  if (n) hipLaunchKernelGGL(digits_hist_kernel, dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, sc, xy, n, digits, flips, hist);
+  if (n) hipLaunchKernelGGL(hist_kernel, dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, sc, xy, n, hist);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, c->stream, hist, offsets, cursor, (int)nb);
-  if (n) hipLaunchKernelGGL(scatter_kernel, dim3(ecgpu_grid_for(c, (size_t)NWIN * n, 8)), dim3(256), 0, c->stream, digits, flips, n, cursor, sorted);
+  if (n) hipLaunchKernelGGL(scatter_kernel, dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, sc, xy, n, cursor, sorted);
   hipLaunchKernelGGL(bucket_sum_kernel, dim3(ecgpu_grid_for(c, nb, 16)), dim3(256), 0, c->stream, xy, offsets, sorted, buckets, (int)nb);
-  hipLaunchKernelGGL(segment_kernel, dim3((NWIN * NSEG + 63) / 64), dim3(64), 0, c->stream, buckets, seg_t, seg_w);
-  hipLaunchKernelGGL(window_kernel, dim3(1), dim3(64), 0, c->stream, seg_t, seg_w, win);
+  hipLaunchKernelGGL(segment_kernel, dim3((unsigned)((n0 + 63) / 64)), dim3(64), 0, c->stream, buckets, t0, w0, SEG0, (int)n0);
+  hipLaunchKernelGGL(segment_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, c->stream, t0, t1, w1, SEG1, (int)n1);
+  hipLaunchKernelGGL(sum_kernel, dim3((unsigned)((nsw + 63) / 64)), dim3(64), 0, c->stream, w0, sumw0, SUMW_LEN, (int)nsw);
+  hipLaunchKernelGGL(window_kernel, dim3(1), dim3(64), 0, c->stream, t1, w1, sumw0, win);
   hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, c->stream, win, out, out_fmt);
   HIPCHK(c, hipGetLastError());
   return 0;
