@@ -309,6 +309,75 @@ __device__ __forceinline__ void k256_fast_finish(const JacK256* res, FeK256* pre
   }
 }
 
+// Two-term linear combination k0*P0 + k1*P1 sharing the 128 doublings (LinearCombination::lincomb,
+// k256 mul.rs:313-323 with N = 2: the ECDSA-verify shape u1*G + u2*Q).  Each term gets its own common-Z
+// table; the two tables live on curves isomorphic by different factors, so each is rescaled by the other's
+// factor (x u^2, y u^3) to put both on the curve isomorphic by zfix0 * zfix1.
+__device__ __forceinline__ void k256_fast_rescale(TabSlotK256* tab, const FeK256& s) {
+  FeK256 s2, s3;
+  k256::sqr(s2, s);
+  k256::mul(s3, s2, s);
+#pragma unroll 1
+  for (int j = 0; j < 8; j++) {
+    FeK256 y;
+    k256::mul(tab[2 * j].x, tab[2 * j].x, s2);
+    k256::mul(tab[2 * j + 1].x, tab[2 * j + 1].x, s2);
+    k256::mul(y, tab[2 * j].y, s3);
+    tab[2 * j].y = y; tab[2 * j + 1].y = y;
+  }
+}
+
+template <int BATCH, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k256_lincomb2_fast_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out,
+                                                                 int out_fmt, uint8_t* out_inf, size_t n, TabSlotK256* table_ws) {
+  TabSlotK256* tab = table_ws + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (2 * K256_TAB_SLOTS);
+  K256FastPrep prep[2];
+  JacK256 res[BATCH];
+  FeK256 pre[BATCH];
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int pw = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * 8;
+  for (size_t base = tid; base < n; base += T * BATCH) {
+    int cnt = 0;
+#pragma unroll 1
+    for (int j = 0; j < BATCH; j++) {
+      const size_t i = base + (size_t)j * T;
+      if (i >= n) break;
+#pragma unroll 1
+      for (int t = 0; t < 2; t++) k256_fast_prep(&prep[t], tab + t * K256_TAB_SLOTS, scalars + (2 * i + t) * 8, points + (2 * i + t) * pw, pt_fmt);
+#pragma unroll 1
+      for (int t = 0; t < 2; t++) k256_fast_rescale(tab + t * K256_TAB_SLOTS, prep[1 - t].zfix);
+      JacK256 acc;
+      k256::set_zero(acc.x); k256::set_zero(acc.y); k256::set_zero(acc.z);
+#pragma unroll 1
+      for (int w = 32; w >= 0; w--) {
+        if (w != 32) {
+#pragma unroll 1
+          for (int d = 0; d < 4; d++) k256::jac_double(acc);
+        }
+#pragma unroll 1
+        for (int h = 0; h < 4; h++) {
+          const K256FastPrep* pp = &prep[h >> 1];
+          const u32* y = (h & 1) ? pp->y2 : pp->y1;
+          u32 word = y[0];
+#pragma unroll
+          for (int q = 1; q < 4; q++) word = (w >> 3) == q ? y[q] : word;
+          int dg = k256::radix16_digit(word, w & 7);
+          if (w == 32) dg = (int)((h & 1) ? pp->top2 : pp->top1);
+          if (pp->p_inf) dg = 0;                       // an identity input contributes nothing
+          k256::add_digit(acc, tab + (h >> 1) * K256_TAB_SLOTS, dg, (h & 1) != 0, ((h & 1) ? pp->neg2 : pp->neg1) != 0);
+        }
+      }
+      FeK256 zf;
+      k256::mul(zf, prep[0].zfix, prep[1].zfix);
+      k256::mul(acc.z, acc.z, zf);
+      res[j] = acc;
+      cnt = j + 1;
+    }
+    k256_fast_finish(res, pre, cnt, base, T, out, out_fmt, out_inf);
+  }
+}
+
 template <int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k256_mul_fast_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out,
                                                             int out_fmt, uint8_t* out_inf, size_t n, TabSlotK256* table_ws) {

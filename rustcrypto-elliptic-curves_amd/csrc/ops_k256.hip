@@ -6,19 +6,25 @@ using namespace ecgpu;
 template <>
 int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt,
                                       uint8_t* out_inf, size_t n) {
-  if (terms != 1) return 0;
-  if (!pts) return mul_gen_fast(c, sc, out, out_fmt, out_inf, n);
+  if (terms == 1 && !pts) return mul_gen_fast(c, sc, out, out_fmt, out_inf, n);
+  if (terms != 1 && terms != 2) return 0;
+  if (!pts) return 0;
   // ECGPU_K256_FAST_WAVES (2/3/4) picks the occupancy variant; default chosen from measurements (profiles/r01_kbench_variants.txt)
   static const int waves = [] { const char* e = getenv("ECGPU_K256_FAST_WAVES"); int w = e ? atoi(e) : 4; return (w < 3 || w > 4) ? 4 : w; }();
-  const unsigned grid = ecgpu_grid_for(c, n, waves);
+  const unsigned grid = ecgpu_grid_for(c, n, terms == 2 ? 4 : waves);
   // per-lane table workspace: 1 KB per resident lane (268 MB at 4 waves/SIMD on 256 CUs), grow-only
-  const size_t ws_need = (size_t)grid * 256 * K256_TAB_SLOTS * sizeof(TabSlotK256);
+  const size_t ws_need = (size_t)grid * 256 * K256_TAB_SLOTS * sizeof(TabSlotK256) * terms;
   if (ws_need > c->tab_ws_cap) {
     if (c->tab_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->tab_ws)); c->tab_ws = nullptr; c->tab_ws_cap = 0; }
     HIPCHK(c, hipMalloc(&c->tab_ws, ws_need));
     c->tab_ws_cap = ws_need;
   }
   TabSlotK256* ws = (TabSlotK256*)c->tab_ws;
+  if (terms == 2) {
+    hipLaunchKernelGGL((k256_lincomb2_fast_kernel<16, 4>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
+    HIPCHK(c, hipGetLastError());
+    return 1;
+  }
   if (waves == 3)
     hipLaunchKernelGGL((k256_mul_fast_kernel<16, 3>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
   else

@@ -178,6 +178,20 @@ def test_lincomb_two_terms(curve):
         a = M.affine_add(C, M.affine_mul(C, ks[2 * i], M.to_affine_opt(C, ps[2 * i])),
                          M.affine_mul(C, ks[2 * i + 1], M.to_affine_opt(C, ps[2 * i + 1])))
         assert bytes(xy[i]) == M.i2b(C, a[0]) + M.i2b(C, a[1])
+    # throughput schedule on the awkward cases: equal points (the doubling branch of the mixed addition),
+    # opposite points, identity inputs, zero scalars
+    G = (C.gx, C.gy)
+    Q = synth.point(C, 1, seed=99)
+    cases = [(5, G, 5, G), (7, G, 7, M.affine_neg(C, G)), (3, Q, N - 3, Q), (11, None, 13, Q), (17, Q, 19, None), (0, G, 0, Q),
+             (1, G, 1, Q), (N - 1, G, 1, G), (2**128, Q, 2**128 + 1, G), (rng.randrange(N), Q, rng.randrange(N), Q)]
+    kk, pp = [], []
+    for k0, p0, k1, p1 in cases:
+        kk += [k0, k1]
+        pp += [bytes(64) if p0 is None else M.i2b(C, p0[0]) + M.i2b(C, p0[1]), bytes(64) if p1 is None else M.i2b(C, p1[0]) + M.i2b(C, p1[1])]
+    xy, inf = curve.lincomb(fe_bytes(kk), np.frombuffer(b"".join(pp), dtype=np.uint8).reshape(-1, 64).copy(), terms=2)
+    for i, (k0, p0, k1, p1) in enumerate(cases):
+        a = M.affine_add(C, M.affine_mul(C, k0, p0), M.affine_mul(C, k1, p1))
+        assert bytes(xy[i]) + bytes([inf[i]]) == M.affine_bytes(C, (0, 0, 1) if a is None else (a[0], a[1], 0)), i
 
 
 def test_validate_and_decompress(curve):

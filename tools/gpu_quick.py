@@ -20,6 +20,17 @@ cv.synth_scalars_device(d_s, n, synth.SEED)
 if mode == "var":
     cv.synth_points_device(d_p, n, synth.SEED)
 ctx.synchronize()
+if mode == "lincomb2":
+    d_s2 = torch.empty((2 * n, nb), dtype=torch.uint8, device="cuda"); d_p2 = torch.empty((2 * n, 2 * nb), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_s2, 2 * n, synth.SEED); cv.synth_points_device(d_p2, 2 * n, synth.SEED); ctx.synchronize()
+    import ctypes
+    for rep in range(3):
+        ctx.timer_start()
+        ctx.check(ctx.lib.ecgpu_lincomb_batch(ctx.handle, cv.id, ctypes.c_void_p(d_s2.data_ptr()), ctypes.c_void_p(d_p2.data_ptr()), 0, 2,
+                                              ctypes.c_void_p(d_o.data_ptr()), 0, ctypes.c_void_p(d_i.data_ptr()), n, 1, flags))
+        ms = ctx.timer_stop()
+        print(f"{cn} lincomb2 {'ref' if flags else 'default'}: n=2^{lg} {ms:.2f} ms  {n/ms*1e3/1e6:.3f} M lincombs/s", flush=True)
+    sys.exit(0)
 if mode == "msm":
     cv.synth_points_device(d_p, n, synth.SEED); ctx.synchronize()
     d_r = torch.empty((64,), dtype=torch.uint8, device="cuda")
