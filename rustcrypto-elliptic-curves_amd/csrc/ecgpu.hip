@@ -109,6 +109,7 @@ void ecgpu_destroy(ecgpu_ctx* c) {
   for (int i = 0; i < 6; i++) if (c->stage[i]) (void)hipFree(c->stage[i]);
   for (int i = 0; i < 3; i++) if (c->gen_table[i]) (void)hipFree(c->gen_table[i]);
   for (int i = 0; i < 3; i++) if (c->fb_table[i]) (void)hipFree(c->fb_table[i]);
+  for (int i = 0; i < 3; i++) if (c->fb16_table[i]) (void)hipFree(c->fb16_table[i]);
   if (c->msm_ws) (void)hipFree(c->msm_ws);
   if (c->tab_ws) (void)hipFree(c->tab_ws);
   if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -20,6 +20,10 @@ namespace fb {
 constexpr int W = 8;
 constexpr int ENTRIES = 1 << (W - 1);                                   // |digit| in 1..128
 template <class C> constexpr int nwin() { return C::NB + 1; }            // one byte per window + the carry window
+// wide variant: 16-bit windows, 2^15 entries per window (35 MB per 256-bit curve: served from the
+// Infinity Cache rather than L2), half as many additions
+constexpr int W16_ENTRIES = 1 << 15;
+template <class C> constexpr int nwin16() { return C::NB / 2 + 1; }
 
 // stage A: one lane per window computes d * 2^(8j) G, d = 1..128, in Jacobian coordinates
 template <class C>
@@ -107,6 +111,141 @@ __global__ void __launch_bounds__(256, WAVES) mul_kernel(const u32* scalars, con
     }
     typename C::Fe ai;
     C::fe_inv(ai, acc);
+#pragma unroll 1
+    for (int b = cnt - 1; b >= 0; b--) {
+      const size_t i = base + (size_t)b * T;
+      typename C::Fe z = res[b].z, one, zero, zi, t, x, y;
+      C::fe_one(one); C::fe_zero(zero);
+      const bool zr = C::fe_is_zero(z);
+      if (zr) z = one;
+      C::fe_mul(zi, ai, pre[b]);
+      C::fe_mul(ai, ai, z);
+      C::fe_sqr(t, zi);
+      C::fe_mul(x, res[b].x, t);
+      C::fe_mul(t, t, zi);
+      C::fe_mul(y, res[b].y, t);
+      if (zr) { x = zero; y = zero; }
+      if (out_fmt == FMT_PROJECTIVE) {
+        if (zr) y = one;
+        u32* o = out + i * 3 * NW;
+        C::fe_store(o, x); C::fe_store(o + NW, y); C::fe_store(o + 2 * NW, zr ? zero : one);
+      } else {
+        u32* o = out + i * 2 * NW;
+        C::fe_store(o, x); C::fe_store(o + NW, y);
+        if (out_inf) out_inf[i] = zr ? 1 : 0;
+      }
+    }
+  }
+}
+
+
+// canonical x||y bytes -> table entries in the internal field form (used to build the wide table
+// from the output of the 8-bit-window kernel itself)
+template <class C>
+__global__ void __launch_bounds__(256) table_from_bytes_kernel(const u32* xy, AffEntry<C>* table, size_t total) {
+  ECGPU_GRID_STRIDE(e, total) {
+    C::fe_load(table[e].x, xy + e * 2 * C::NW);
+    C::fe_load(table[e].y, xy + e * 2 * C::NW + C::NW);
+  }
+}
+// scalars d * 2^(16 j) for j < nwin16, d = 1..2^15 (canonical big-endian bytes), reduced mod n
+template <class C>
+__global__ void __launch_bounds__(256) table_scalars_kernel(u32* out, size_t total) {
+  constexpr int NW = C::NW;
+  ECGPU_GRID_STRIDE(e, total) {
+    const int j = (int)(e / W16_ENTRIES);
+    u32 d = (u32)(e % W16_ENTRIES) + 1;
+    // the carry window only ever sees digit 1 (k <= n/2 after the sign fold): its other entries are never read
+    const bool carry_window = (j == nwin16<C>() - 1);
+    if (carry_window && d > 1) d = 1;
+    u32 k[NW + 1];
+#pragma unroll
+    for (int w = 0; w <= NW; w++) k[w] = 0;
+    // d << (16 j): d <= 2^15 spans at most two 32-bit words
+#pragma unroll
+    for (int w = 0; w <= NW; w++) {
+      if (w == (j >> 1)) k[w] |= (j & 1) ? (d << 16) : d;
+      if (w == (j >> 1) + 1 && (j & 1)) k[w] |= d >> 16;
+    }
+    // j = nwin16 - 1 gives d * 2^(8 NB) which exceeds the word array: reduce 2^(32 NW) = R mod n by subtraction
+    u32 ord[NW];
+    C::order(ord);
+    if (k[NW]) {
+      // value = k[NW] * 2^(32 NW) + low;  2^(32 NW) mod n = 2^(32 NW) - n  (n > 2^(32 NW - 1))
+      u32 negn[NW], acc[NW], bw = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) negn[w] = subb(0u, ord[w], bw);      // 2^(32 NW) - n
+      mp_zero<NW>(acc);
+      for (u32 t = 0; t < k[NW]; t++) { mp_add<NW>(acc, acc, negn); reduce_once<NW>(acc, ord); }
+      u32 lo[NW];
+#pragma unroll
+      for (int w = 0; w < NW; w++) lo[w] = k[w];
+      reduce_once<NW>(lo, ord);
+      const u32 cy = mp_add<NW>(acc, acc, lo);
+      if (cy) { u32 t2[NW]; mp_sub<NW>(t2, acc, ord); mp_copy<NW>(acc, t2); }
+      reduce_once<NW>(acc, ord);
+#pragma unroll
+      for (int w = 0; w < NW; w++) k[w] = acc[w];
+    } else {
+      reduce_once<NW>(k, ord);
+    }
+    words_store_be<NW>(out + e * NW, k);
+  }
+}
+
+template <class C, int BATCH, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) mul16_kernel(const u32* scalars, const AffEntry<C>* table, u32* out, int out_fmt,
+                                                           uint8_t* out_inf, size_t n) {
+  constexpr int NW = C::NW;
+  Jac<C> res[BATCH];
+  typename C::Fe pre[BATCH];
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t base = tid; base < n; base += T * BATCH) {
+    int cnt = 0;
+#pragma unroll 1
+    for (int b = 0; b < BATCH; b++) {
+      const size_t i = base + (size_t)b * T;
+      if (i >= n) break;
+      u32 k[NW], ord[NW], t[NW];
+      C::scalar_load(k, scalars + i * NW);
+      C::order(ord);
+      reduce_once<NW>(k, ord);
+      mp_sub<NW>(t, ord, k);
+      const bool flip = !mp_geq<NW>(t, k);
+#pragma unroll
+      for (int w = 0; w < NW; w++) k[w] = flip ? t[w] : k[w];
+      Jac<C> acc;
+      jac::set_infinity<C>(acc);
+      u32 carry = 0;
+#pragma unroll 1
+      for (int j = 0; j < nwin16<C>(); j++) {
+        u32 word = 0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) word = (j >> 1) == q ? k[q] : word;
+        u32 d = ((j < 2 * NW) ? ((word >> (16 * (j & 1))) & 0xFFFFu) : 0u) + carry;
+        carry = (d >= 0x8000u) ? 1u : 0u;
+        const int sd = (int)d - (int)(carry << 16);
+        if (sd != 0) {
+          const AffEntry<C>* e = table + (size_t)j * W16_ENTRIES + ((sd < 0 ? -sd : sd) - 1);
+          typename C::Fe x = e->x, y = e->y;
+          if ((sd < 0) != flip) C::fe_neg(y, y);
+          jac::add_mixed<C>(acc, x, y);
+        }
+      }
+      res[b] = acc;
+      cnt = b + 1;
+    }
+    typename C::Fe accz; C::fe_one(accz);
+#pragma unroll 1
+    for (int b = 0; b < cnt; b++) {
+      pre[b] = accz;
+      typename C::Fe z = res[b].z;
+      if (C::fe_is_zero(z)) C::fe_one(z);
+      C::fe_mul(accz, accz, z);
+    }
+    typename C::Fe ai;
+    C::fe_inv(ai, accz);
 #pragma unroll 1
     for (int b = cnt - 1; b >= 0; b--) {
       const size_t i = base + (size_t)b * T;

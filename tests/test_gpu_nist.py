@@ -200,3 +200,33 @@ def test_validate_and_decompress(ctx, cn):
             assert okd[i] == 0 and not out[i].any()
         else:
             assert okd[i] == 1 and bytes(out[i]) == M.i2b(c, want[0]) + M.i2b(c, want[1])
+
+
+@pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1), ("p384", 2)])
+def test_fixed_base_wide_table_path(ctx, cn, cid):
+    """Batches of 2^18 and more take the 16-bit-window table (fixedbase.hpp): edge scalars up front, a seeded
+    batch behind them, sampled against the C oracle (reference mul_by_generator)."""
+    import torch
+    c = M.CURVES[cn]
+    cv = ctx.curve(cn)
+    nb = c.nbytes
+    n = 1 << 18
+    edge = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, (c.n + 1) // 2, 0x8000, 0x7FFF, 0xFFFF, 0x10000, 0x80008000, (1 << (8 * nb - 1)) % c.n,
+            (0x7FFF << (8 * nb - 16)) | ((1 << (8 * nb - 16)) - 1), c.n - 0x8000, c.n - 0x7FFF, int("8000" * (nb // 2), 16) % c.n,
+            int("7FFF" * (nb // 2), 16), int("FFFF" * (nb // 2), 16) % c.n]
+    d_s = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_s, n, synth.SEED, 424242)
+    ctx.synchronize()
+    s = d_s.cpu().numpy()
+    for i, k in enumerate(edge):
+        s[i] = np.frombuffer(int(k).to_bytes(nb, "big"), dtype=np.uint8)
+    d_s.copy_(torch.from_numpy(s))
+    d_o = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+    d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    cv.mul_device(d_s, None, d_o, n, d_out_inf=d_i)
+    ctx.synchronize()
+    o, inf = d_o.cpu().numpy(), d_i.cpu().numpy()
+    idx = list(range(len(edge))) + list(range(len(edge), n, n // 300))
+    want = CO.lincomb_batch(cid, s[idx].copy(), None, threads=4)
+    got = np.concatenate([o[idx], inf[idx][:, None]], axis=1)
+    assert bytes(got) == bytes(want)
