@@ -56,8 +56,8 @@ WORKLOADS = {
                            modmul=None, mac=64, bytes_per_unit=32 + 64 + 65, kernel=None,
                            desc="k256 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
     "p256_fixedbase": dict(curve="p256", cid=1, log2n=24, fixed=True, msm=False, metric="p256 fixed-base (mul_by_generator) scalar-muls/sec", unit="scalar-muls/s",
-                           # 33 signed 8-bit windows: ~32.9 mixed additions (8M+3S) + batched normalise 6M+1S + (256S+128M)/16
-                           modmul=33 * 11 + 7 + 24, mac=64, bytes_per_unit=32 + 65, kernel="fb::mul_kernel<CurveP256,16,4>",
+                           # batches >= 2^18: 17 signed 16-bit windows -> ~17 mixed additions (8M+3S) + batched normalise 6M+1S + (256S+128M)/16
+                           modmul=17 * 11 + 7 + 24, mac=64, bytes_per_unit=32 + 65, kernel="fb::mul16_kernel<CurveP256,16,4>",
                            desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
     "p384_varbase":   dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
                            # 96 windows x (4 doublings (3M+5S) + 15/16 general additions (11M+5S)) + table (4 dbl + 3 add) + normalise
