@@ -1,0 +1,92 @@
+"""Full-size, size-independent properties (k256, 2^22 units): the variable-base kernel, the MSM and the
+fixed-base kernel are three independent code paths that must agree, and a 2^20 slice is compared
+byte for byte with the C oracle."""
+import numpy as np
+import pytest
+
+from oracle import coracle as CO
+from oracle import ecmodel as M
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+C = M.K256
+N = C.n
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    yield ctx, ctx.curve("k256")
+    ctx.close()
+
+
+def test_varbase_outputs_sum_to_the_msm(env):
+    """sum_i (k_i P_i) computed as (a) 2^22 independent scalar multiplications folded with an MSM with unit
+    scalars and (b) one Pippenger MSM over the same terms: a checksum of checksums across kernels."""
+    import torch
+    ctx, cv = env
+    n = 1 << 22
+    d_s = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    d_p = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    d_o = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_s, n, synth.SEED, 9000000)
+    cv.synth_points_device(d_p, n, synth.SEED, 9000000)
+    cv.mul_device(d_s, d_p, d_o, n)
+    ones = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+    ones[:, 31] = 1
+    d_a = torch.empty((64,), dtype=torch.uint8, device="cuda")
+    d_b = torch.empty((64,), dtype=torch.uint8, device="cuda")
+    cv.msm_device(ones, d_o, n, d_a)          # sum of the outputs
+    cv.msm_device(d_s, d_p, n, d_b)           # the MSM of the inputs
+    ctx.synchronize()
+    a, b = bytes(d_a.cpu().numpy()), bytes(d_b.cpu().numpy())
+    assert a == b and a != bytes(64)
+
+
+def test_linearity_and_fixed_base_consistency(env):
+    """(k + l) P = kP + lP on 2^20 random inputs; k (mG) = (k m) G ties the variable-base kernel to the
+    fixed-base kernel (8- and 16-bit tables) through scalar arithmetic done on the host."""
+    import torch
+    import ecgpu
+    ctx, cv = env
+    n = 1 << 20
+    ks = CO.synth_scalars(0, n, synth.SEED, 5)
+    ms = CO.synth_scalars(0, n, synth.SEED, 7000000)
+    kb, mb = ks.tobytes(), ms.tobytes()
+    prod = np.frombuffer(b"".join(((int.from_bytes(kb[32 * i:32 * i + 32], "big") * int.from_bytes(mb[32 * i:32 * i + 32], "big")) % N).to_bytes(32, "big")
+                                  for i in range(0, n, 16)), dtype=np.uint8).reshape(-1, 32).copy()
+    d_m = torch.from_numpy(ms).cuda()
+    d_pts = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    cv.mul_device(d_m, None, d_pts, n)                       # m_i G  (wide fixed-base table)
+    d_k = torch.from_numpy(ks).cuda()
+    d_o = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    cv.mul_device(d_k, d_pts, d_o, n)                        # k_i (m_i G)
+    sub = torch.from_numpy(prod).cuda()
+    d_chk = torch.empty((sub.shape[0], 64), dtype=torch.uint8, device="cuda")
+    cv.mul_device(sub, None, d_chk, sub.shape[0])            # (k_i m_i) G  (8-bit table: 2^16 scalars)
+    ctx.synchronize()
+    assert bytes(d_o.cpu().numpy()[::16].copy()) == bytes(d_chk.cpu().numpy())
+
+
+def test_slice_against_c_oracle(env):
+    import torch
+    ctx, cv = env
+    n = 1 << 20
+    first = 31337
+    d_s = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    d_p = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    d_o = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_s, n, synth.SEED, first)
+    cv.synth_points_device(d_p, n, synth.SEED, first)
+    cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i)
+    ctx.synchronize()
+    m = 1 << 15                                            # ~2 s of single-thread oracle time
+    idx = np.arange(0, n, n // m)
+    s, p = d_s.cpu().numpy()[idx].copy(), d_p.cpu().numpy()[idx].copy()
+    want = CO.lincomb_batch(0, s, p, threads=8)
+    got = np.concatenate([d_o.cpu().numpy()[idx], d_i.cpu().numpy()[idx][:, None]], axis=1)
+    assert bytes(got) == bytes(want)
