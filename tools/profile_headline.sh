@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collect the evidence behind bench.py's roofline object for the headline workload, on the GPU box:
+#   gpurun --timeout 1100 -- 'bash tools/profile_headline.sh'
+# 1. kernel trace + stats of the bench command, 2. PMC counters, one group per pass (never combined with
+# traces), 3. tools/pmc_summarize.py folds them into gpurun_out/pmc_summary.json.
+# Copy the summaries you want judged into profiles/ afterwards.
+set -e
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+OUT=gpurun_out/headline
+rm -rf "$OUT"; mkdir -p "$OUT"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/trace.log" 2>&1
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES" \
+           "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY"; do
+  tag=$(echo "$grp" | tr ' ' '+')
+  echo "[pmc] $grp"
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$tag" -- python3 $ARGS > "$OUT/pmc_$tag.log" 2>&1
+done
+python3 tools/pmc_summarize.py "$OUT" "${KERNEL_MATCH:-k256_mul_fast_kernel}" > gpurun_out/pmc_summary.json
+cat gpurun_out/pmc_summary.json
