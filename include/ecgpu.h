@@ -80,7 +80,11 @@ enum {
    * 4-bit window for p256/p384) so that a PROJECTIVE result is the very (X, Y, Z) triple the
    * reference returns.  Without it the library is free to pick the fastest schedule and only
    * the group element (hence the affine result) is specified. */
-  ECGPU_EXACT_REFERENCE = 1u
+  ECGPU_EXACT_REFERENCE = 1u,
+  /* ECDSA on secp256k1 as the reference configures it: verification rejects s > n/2
+   * (k256/src/ecdsa.rs:199-207), signing normalises s to the low half and flips the recovery
+   * parity (k256/src/ecdsa.rs:182-196).  The NIST curves are used without it. */
+  ECGPU_ECDSA_LOW_S = 2u
 };
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -151,6 +155,25 @@ int ecgpu_validate_points(ecgpu_ctx* ctx, int curve, const uint8_t* points_xy, u
  * out_xy[i] = (x, y) with y parity y_is_odd[i]; ok[i] = 0 (and zeros) when x >= p or no root. */
 int ecgpu_decompress_batch(ecgpu_ctx* ctx, int curve, const uint8_t* x, const uint8_t* y_is_odd,
                            uint8_t* out_xy, uint8_t* ok, size_t n, int mem);
+
+/* ---- ECDSA over the path (the callers of mul_by_generator / lincomb) ---------------------------
+ * VerifyPrimitive::verify_prehashed / SignPrimitive::try_sign_prehashed; the primitives are the
+ * external ecdsa 0.16.9 hazmat functions entered from k256/src/ecdsa.rs:182-209,
+ * p256/src/ecdsa.rs:72-75, p384/src/ecdsa.rs:69-72.
+ *   prehash     n x field_bytes: the message digest after bits2field (left-most field_bytes bytes,
+ *               zero-padded on the left when shorter)
+ *   sig_rs      n x 2 field_bytes: r || s, the fixed-size Signature::to_bytes form
+ *   pubkeys_xy  n x 2 field_bytes affine x || y
+ * ok[i] = 1 iff signature i verifies.  Like the reference, r or s outside [1, n-1], a public key
+ * that is off the curve, non-canonical or the identity, and R = identity all give 0. */
+int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* prehash, const uint8_t* sig_rs,
+                             const uint8_t* pubkeys_xy, uint8_t* ok, size_t n, int mem, unsigned flags);
+/* sig_rs[i] = (r, s) with R = k G, r = x(R) mod n, s = k^-1 (z + r d) mod n; recovery_id[i] (optional) =
+ * y_is_odd(R) | x_is_reduced << 1; ok[i] = 0 (and a zero signature) when d or k is outside [1, n-1]
+ * or r = 0 or s = 0, where the reference returns Err. */
+int ecgpu_ecdsa_sign_batch(ecgpu_ctx* ctx, int curve, const uint8_t* secret_d, const uint8_t* nonce_k,
+                           const uint8_t* prehash, uint8_t* sig_rs, uint8_t* recovery_id, uint8_t* ok,
+                           size_t n, int mem, unsigned flags);
 
 /* ---- synthetic inputs for benchmarks (device memory only) ------------------------------------
  * Fill device buffers with the counter-based streams specified in oracle/synth.py:

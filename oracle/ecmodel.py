@@ -593,3 +593,56 @@ def affine_bytes(c: Curve, A) -> bytes:
     """x || y || infinity-byte (x = y = 0 when infinity, as AffinePoint::IDENTITY)."""
     x, y, inf = A
     return i2b(c, x) + i2b(c, y) + bytes([inf])
+
+
+# --- ECDSA over the path (callers of mul_by_generator / lincomb; SURVEY.md section 8f rank 3) ------------------
+# The primitives live in the external `ecdsa` crate 0.16.9 (hazmat::{sign_prehashed, verify_prehashed, bits2field}),
+# entered from k256/src/ecdsa.rs:182-209, p256/src/ecdsa.rs:72-75, p384/src/ecdsa.rs:69-72.  Restated from the
+# published algorithm (SEC1 v2 4.1.3 / 4.1.4) and pinned by the in-tree ECDSA KATs and Wycheproof blobs.
+
+def bits2field(c: Curve, digest: bytes) -> bytes:
+    """Left-most field-size bytes of the digest, zero-padded on the left when shorter (digests shorter than
+    half the field size are an error in the reference)."""
+    fb = c.nbytes
+    if len(digest) < fb // 2:
+        raise ValueError("digest too short")
+    if len(digest) >= fb:
+        return digest[:fb]
+    return bytes(fb - len(digest)) + digest
+
+
+def ecdsa_verify_prehashed(c: Curve, Q, z: bytes, r: int, s: int, reject_high_s: bool = False) -> bool:
+    """Q affine (x, y) on the curve; z = bits2field(prehash); r, s integers.  k256's VerifyPrimitive rejects
+    high s first (k256/src/ecdsa.rs:199-207)."""
+    n = c.n
+    if not (0 < r < n and 0 < s < n):
+        return False                      # Signature::from_scalars: both non-zero, canonical
+    if reject_high_s and s > n // 2:
+        return False
+    e = int.from_bytes(z, "big") % n      # Reduce::reduce_bytes
+    w = pow(s, -1, n)
+    u1, u2 = e * w % n, r * w % n
+    R = affine_add(c, affine_mul(c, u1, (c.gx, c.gy)), affine_mul(c, u2, Q))
+    if R is None:
+        return False                      # identity: to_affine().x() = 0, reduces to 0 != r
+    return R[0] % n == r
+
+
+def ecdsa_sign_prehashed(c: Curve, d: int, k: int, z: bytes, normalize_s: bool = False):
+    """(r, s, recovery id) or None.  recovery id = y_is_odd | x_reduced << 1; k256 normalises s to the low half and
+    flips y_is_odd (k256/src/ecdsa.rs:182-196)."""
+    n = c.n
+    if not (0 < k < n):
+        return None
+    e = int.from_bytes(z, "big") % n
+    R = affine_mul(c, k, (c.gx, c.gy))
+    r = R[0] % n
+    s = pow(k, -1, n) * (e + r * d) % n
+    if r == 0 or s == 0:
+        return None
+    y_odd = R[1] & 1
+    x_reduced = 1 if R[0] >= n else 0
+    if normalize_s and s > n // 2:
+        s = n - s
+        y_odd ^= 1
+    return r, s, y_odd | (x_reduced << 1)

@@ -4,6 +4,7 @@
 #include "ecgpu_internal.hpp"
 #include "kernels.hpp"
 #include "fixedbase.hpp"
+#include "ecdsa_kernels.hpp"
 
 namespace ecgpu {
 
@@ -153,9 +154,52 @@ struct CurveOps {
     HIPCHK(c, hipGetLastError());
     return 0;
   }
+  // ECDSA pipelines (ecdsa_kernels.hpp): the scalar multiplications run on the throughput kernels above
+  static int ecdsa_reserve(ecgpu_ctx* c, size_t need) {
+    if (need <= c->ecdsa_ws_cap) return 0;
+    if (c->ecdsa_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->ecdsa_ws)); c->ecdsa_ws = nullptr; c->ecdsa_ws_cap = 0; }
+    HIPCHK(c, hipMalloc(&c->ecdsa_ws, need));
+    c->ecdsa_ws_cap = need;
+    return 0;
+  }
+  static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+  static int ecdsa_verify(ecgpu_ctx* c, const u32* z, const u32* sig, const u32* q, uint8_t* ok, size_t n, unsigned flags) {
+    const size_t sz_s = al256(n * C::NB), sz_p = al256(n * 2 * C::NB), sz_f = al256(n);
+    int rc = ecdsa_reserve(c, 2 * sz_s + 2 * sz_p + 2 * sz_f);
+    if (rc) return rc;
+    char* p = (char*)c->ecdsa_ws;
+    u32* u1 = (u32*)p; p += sz_s;
+    u32* u2 = (u32*)p; p += sz_s;
+    u32* a = (u32*)p; p += sz_p;
+    u32* b = (u32*)p; p += sz_p;
+    uint8_t* a_inf = (uint8_t*)p; p += sz_f;
+    uint8_t* b_inf = (uint8_t*)p;
+    hipLaunchKernelGGL((ecdsa::verify_prep_kernel<C, 16>), dim3(ecgpu_grid_for(c, (n + 15) / 16, 4)), dim3(256), 0, c->stream, z, sig, q, u1, u2,
+                       ok, n, flags);
+    HIPCHK(c, hipGetLastError());
+    if ((rc = lincomb(c, u1, nullptr, FMT_AFFINE, 1, a, FMT_AFFINE, a_inf, n, 0))) return rc;
+    if ((rc = lincomb(c, u2, q, FMT_AFFINE, 1, b, FMT_AFFINE, b_inf, n, 0))) return rc;
+    hipLaunchKernelGGL((ecdsa::verify_check_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, (const u32*)a,
+                       (const uint8_t*)a_inf, (const u32*)b, (const uint8_t*)b_inf, sig, ok, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static int ecdsa_sign(ecgpu_ctx* c, const u32* d, const u32* k, const u32* z, u32* sig, uint8_t* recid, uint8_t* ok, size_t n,
+                        unsigned flags) {
+    const size_t sz_p = al256(n * 2 * C::NB), sz_f = al256(n);
+    int rc = ecdsa_reserve(c, sz_p + sz_f);
+    if (rc) return rc;
+    u32* r_xy = (u32*)c->ecdsa_ws;
+    uint8_t* r_inf = (uint8_t*)c->ecdsa_ws + sz_p;
+    if ((rc = lincomb(c, k, nullptr, FMT_AFFINE, 1, r_xy, FMT_AFFINE, r_inf, n, 0))) return rc;
+    hipLaunchKernelGGL((ecdsa::sign_finish_kernel<C, 16>), dim3(ecgpu_grid_for(c, (n + 15) / 16, 4)), dim3(256), 0, c->stream, d, k, z,
+                       (const u32*)r_xy, (const uint8_t*)r_inf, sig, recid, ok, n, flags);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   static const ecgpu_curve_ops* table() {
     static const ecgpu_curve_ops t = {field_op, point_op, normalize, lincomb, msm, validate_scalars, validate_points,
-                                      decompress, synth_scalars, synth_points};
+                                      decompress, synth_scalars, synth_points, ecdsa_verify, ecdsa_sign};
     return &t;
   }
 };

@@ -112,6 +112,7 @@ void ecgpu_destroy(ecgpu_ctx* c) {
   for (int i = 0; i < 3; i++) if (c->fb16_table[i]) (void)hipFree(c->fb16_table[i]);
   if (c->msm_ws) (void)hipFree(c->msm_ws);
   if (c->tab_ws) (void)hipFree(c->tab_ws);
+  if (c->ecdsa_ws) (void)hipFree(c->ecdsa_ws);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -281,6 +282,44 @@ int ecgpu_decompress_batch(ecgpu_ctx* c, int curve, const uint8_t* x, const uint
   if ((rc = ops->decompress(c, (const uint32_t*)bx.dev, (const uint8_t*)by.dev, (uint32_t*)bo.dev, (uint8_t*)bk.dev, n))) return rc;
   if ((rc = buf_finish(c, bo))) return rc;
   if ((rc = buf_finish(c, bk))) return rc;
+  return finish_host(c, mem);
+}
+
+// ---------------------------------------------------------------------------------------------
+int ecgpu_ecdsa_verify_batch(ecgpu_ctx* c, int curve, const uint8_t* prehash, const uint8_t* sig_rs, const uint8_t* pubkeys_xy, uint8_t* ok,
+                             size_t n, int mem, unsigned flags) {
+  if (!c || !prehash || !sig_rs || !pubkeys_xy || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (n == 0) return ECGPU_OK;
+  ENTER(c, curve);
+  Buf bz, bs, bq, bo;
+  int rc;
+  if ((rc = buf_in(c, bz, 0, prehash, n * nb, mem))) return rc;
+  if ((rc = buf_in(c, bs, 1, sig_rs, n * 2 * nb, mem))) return rc;
+  if ((rc = buf_in(c, bq, 4, pubkeys_xy, n * 2 * nb, mem))) return rc;
+  if ((rc = buf_out(c, bo, 2, ok, n, mem))) return rc;
+  if ((rc = ops->ecdsa_verify(c, (const uint32_t*)bz.dev, (const uint32_t*)bs.dev, (const uint32_t*)bq.dev, (uint8_t*)bo.dev, n, flags))) return rc;
+  if ((rc = buf_finish(c, bo))) return rc;
+  return finish_host(c, mem);
+}
+int ecgpu_ecdsa_sign_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, const uint8_t* nonce_k, const uint8_t* prehash, uint8_t* sig_rs,
+                           uint8_t* recovery_id, uint8_t* ok, size_t n, int mem, unsigned flags) {
+  if (!c || !secret_d || !nonce_k || !prehash || !sig_rs || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (n == 0) return ECGPU_OK;
+  ENTER(c, curve);
+  Buf bd, bk, bz, bs, br, bo;
+  int rc;
+  if ((rc = buf_in(c, bd, 0, secret_d, n * nb, mem))) return rc;
+  if ((rc = buf_in(c, bk, 1, nonce_k, n * nb, mem))) return rc;
+  if ((rc = buf_in(c, bz, 4, prehash, n * nb, mem))) return rc;
+  if ((rc = buf_out(c, bs, 2, sig_rs, n * 2 * nb, mem))) return rc;
+  if ((rc = buf_out(c, br, 3, recovery_id, n, mem))) return rc;
+  if ((rc = buf_out(c, bo, 5, ok, n, mem))) return rc;
+  if ((rc = ops->ecdsa_sign(c, (const uint32_t*)bd.dev, (const uint32_t*)bk.dev, (const uint32_t*)bz.dev, (uint32_t*)bs.dev, (uint8_t*)br.dev,
+                            (uint8_t*)bo.dev, n, flags)))
+    return rc;
+  if ((rc = buf_finish(c, bs))) return rc;
+  if ((rc = buf_finish(c, br))) return rc;
+  if ((rc = buf_finish(c, bo))) return rc;
   return finish_host(c, mem);
 }
 

@@ -32,6 +32,9 @@ struct ecgpu_ctx {
   // MSM workspace (grow-only)
   void* msm_ws = nullptr;
   size_t msm_ws_cap = 0;
+  // intermediate scalars / points of the ECDSA pipelines (grow-only)
+  void* ecdsa_ws = nullptr;
+  size_t ecdsa_ws_cap = 0;
 };
 
 static inline int ecgpu_set_err(ecgpu_ctx* c, int code, const char* fmt, ...) {
@@ -70,6 +73,9 @@ struct ecgpu_curve_ops {
   int (*decompress)(ecgpu_ctx* c, const uint32_t* x, const uint8_t* y_is_odd, uint32_t* out_xy, uint8_t* ok, size_t n);
   int (*synth_scalars)(ecgpu_ctx* c, uint64_t seed, uint64_t first, uint32_t* out, size_t n);
   int (*synth_points)(ecgpu_ctx* c, uint64_t seed, uint64_t first, uint32_t* out_xy, size_t n);
+  int (*ecdsa_verify)(ecgpu_ctx* c, const uint32_t* z, const uint32_t* sig, const uint32_t* q_xy, uint8_t* ok, size_t n, unsigned flags);
+  int (*ecdsa_sign)(ecgpu_ctx* c, const uint32_t* d, const uint32_t* k, const uint32_t* z, uint32_t* sig, uint8_t* recid, uint8_t* ok,
+                    size_t n, unsigned flags);
 };
 const ecgpu_curve_ops* ecgpu_ops_k256();
 const ecgpu_curve_ops* ecgpu_ops_p256();

@@ -26,6 +26,7 @@ except ImportError:  # torch is optional plumbing; the C ABI itself needs only t
 HOST, DEVICE = 0, 1
 AFFINE, PROJECTIVE = 0, 1
 EXACT_REFERENCE = 1
+ECDSA_LOW_S = 2
 K256, P256, P384 = 0, 1, 2
 CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384}
 FIELD_BYTES = {K256: 32, P256: 32, P384: 48}
@@ -75,6 +76,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.ecgpu_validate_scalars.argtypes = [vp, i, u8p, u8p, sz, i]
     lib.ecgpu_validate_points.argtypes = [vp, i, u8p, u8p, sz, i]
     lib.ecgpu_decompress_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i]
+    lib.ecgpu_ecdsa_verify_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
+    lib.ecgpu_ecdsa_sign_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
     lib.ecgpu_synth_scalars.argtypes = [vp, i, ctypes.c_uint64, ctypes.c_uint64, u8p, sz]
     lib.ecgpu_synth_points.argtypes = [vp, i, ctypes.c_uint64, ctypes.c_uint64, u8p, sz]
     for name in ("ecgpu_create", "ecgpu_set_stream", "ecgpu_synchronize", "ecgpu_timer_start", "ecgpu_timer_stop",
@@ -93,7 +96,7 @@ EXPORTED_SYMBOLS = (
     "ecgpu_field_bytes", "ecgpu_timer_start", "ecgpu_timer_stop", "ecgpu_field_op_batch", "ecgpu_point_add_batch",
     "ecgpu_point_add_mixed_batch", "ecgpu_point_double_batch", "ecgpu_batch_normalize", "ecgpu_mul_batch",
     "ecgpu_lincomb_batch", "ecgpu_msm", "ecgpu_validate_scalars", "ecgpu_validate_points", "ecgpu_decompress_batch",
-    "ecgpu_synth_scalars", "ecgpu_synth_points",
+    "ecgpu_synth_scalars", "ecgpu_synth_points", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_sign_batch",
 )
 
 
@@ -269,6 +272,41 @@ class Curve:
         out, ok = _host_out(len(x), 2 * self.nb), np.zeros(len(x), dtype=np.uint8)
         self.ctx.check(self.ctx.lib.ecgpu_decompress_batch(self.ctx.handle, self.id, _ptr(x)[0], _ptr(odd)[0], _ptr(out)[0], _ptr(ok)[0], len(x), HOST))
         return out, ok
+
+    # --- ECDSA: VerifyPrimitive::verify_prehashed / SignPrimitive::try_sign_prehashed ------------------
+    def default_ecdsa_flags(self) -> int:
+        """secp256k1 is used with low-s rules in the reference (k256/src/ecdsa.rs:182-207), the NIST curves are not."""
+        return ECDSA_LOW_S if self.id == K256 else 0
+
+    def ecdsa_verify(self, prehash, sig_rs, pubkeys_xy, flags: Optional[int] = None) -> np.ndarray:
+        z, sg, q = _as_host(prehash, self.nb), _as_host(sig_rs, 2 * self.nb), _as_host(pubkeys_xy, 2 * self.nb)
+        if not (len(z) == len(sg) == len(q)):
+            raise ValueError("prehash, signature and public-key batches differ in length")
+        ok = np.zeros(len(z), dtype=np.uint8)
+        fl = self.default_ecdsa_flags() if flags is None else flags
+        self.ctx.check(self.ctx.lib.ecgpu_ecdsa_verify_batch(self.ctx.handle, self.id, _ptr(z)[0], _ptr(sg)[0], _ptr(q)[0], _ptr(ok)[0], len(z), HOST, fl))
+        return ok
+
+    def ecdsa_verify_device(self, d_prehash, d_sig_rs, d_pubkeys_xy, d_ok, n: int, flags: Optional[int] = None):
+        fl = self.default_ecdsa_flags() if flags is None else flags
+        self.ctx.check(self.ctx.lib.ecgpu_ecdsa_verify_batch(self.ctx.handle, self.id, _ptr(d_prehash)[0], _ptr(d_sig_rs)[0], _ptr(d_pubkeys_xy)[0],
+                                                             _ptr(d_ok)[0], n, DEVICE, fl))
+
+    def ecdsa_sign(self, secret_d, nonce_k, prehash, flags: Optional[int] = None):
+        """-> (sig_rs, recovery_id, ok)"""
+        d, k, z = _as_host(secret_d, self.nb), _as_host(nonce_k, self.nb), _as_host(prehash, self.nb)
+        if not (len(d) == len(k) == len(z)):
+            raise ValueError("key, nonce and prehash batches differ in length")
+        sig, rec, ok = _host_out(len(d), 2 * self.nb), np.zeros(len(d), dtype=np.uint8), np.zeros(len(d), dtype=np.uint8)
+        fl = self.default_ecdsa_flags() if flags is None else flags
+        self.ctx.check(self.ctx.lib.ecgpu_ecdsa_sign_batch(self.ctx.handle, self.id, _ptr(d)[0], _ptr(k)[0], _ptr(z)[0], _ptr(sig)[0], _ptr(rec)[0],
+                                                           _ptr(ok)[0], len(d), HOST, fl))
+        return sig, rec, ok
+
+    def ecdsa_sign_device(self, d_secret, d_nonce, d_prehash, d_sig_rs, d_recid, d_ok, n: int, flags: Optional[int] = None):
+        fl = self.default_ecdsa_flags() if flags is None else flags
+        self.ctx.check(self.ctx.lib.ecgpu_ecdsa_sign_batch(self.ctx.handle, self.id, _ptr(d_secret)[0], _ptr(d_nonce)[0], _ptr(d_prehash)[0],
+                                                           _ptr(d_sig_rs)[0], _ptr(d_recid)[0], _ptr(d_ok)[0], n, DEVICE, fl))
 
     # --- synthetic inputs (device buffers) ---------------------------------------------------------
     def synth_scalars_device(self, d_out, n: int, seed: int, first_index: int = 0):

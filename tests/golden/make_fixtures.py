@@ -63,8 +63,44 @@ def ecdsa_vectors(curve):
     out = []
     for blk in t.split("TestVector {")[1:]:
         fields = dict(re.findall(r'(\w+):\s*&hex!\(\s*"([0-9A-Fa-f]+)"\s*\)', blk))
-        out.append({k: fields[k] for k in ("d", "q_x", "q_y", "k", "r")})
+        out.append({k: fields[k] for k in ("d", "q_x", "q_y", "k", "m", "r", "s")})
     return out
+
+
+def _read_vlq(d, pos):
+    b = d[pos]
+    pos += 1
+    val = b & 0x7F
+    while b & 0x80:
+        b = d[pos]
+        pos += 1
+        val = ((val + 1) << 7) + (b & 0x7F)
+    return val, pos
+
+
+def wycheproof_rows(curve):
+    """<curve>/src/test_vectors/data/wycheproof.blb: a blobby file (de-duplicated blob table, then entries that
+    are either a table reference or an inline blob), five blobs per row: wx, wy, msg, DER signature, pass flag
+    (runner: k256/src/ecdsa.rs:340-425)."""
+    with open(os.path.join(REF, f"{curve}/src/test_vectors/data/wycheproof.blb"), "rb") as f:
+        d = f.read()
+    n, pos = _read_vlq(d, 0)
+    table = []
+    for _ in range(n):
+        ln, pos = _read_vlq(d, pos)
+        table.append(d[pos:pos + ln])
+        pos += ln
+    items = []
+    while pos < len(d):
+        v, pos = _read_vlq(d, pos)
+        if v & 1:
+            items.append(table[v >> 1])
+        else:
+            items.append(d[pos:pos + (v >> 1)])
+            pos += v >> 1
+    assert len(items) % 5 == 0
+    return [[items[i].hex(), items[i + 1].hex(), items[i + 2].hex(), items[i + 3].hex(), items[i + 4][0]]
+            for i in range(0, len(items), 5)]
 
 
 def h2c_vectors(curve):
@@ -122,6 +158,11 @@ def main():
     print(json.dumps(counts, indent=1))
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as f:
         json.dump(fx, f, indent=0, sort_keys=True)
+    for c in ("k256", "p256", "p384"):
+        rows = wycheproof_rows(c)
+        with open(os.path.join(HERE, f"wycheproof_{c}.json"), "w") as f:
+            json.dump({"curve": c, "columns": ["wx", "wy", "msg", "der_sig", "pass"], "rows": rows}, f, indent=0)
+        print("wycheproof", c, len(rows))
     cfg = {
         "k256": config_fixture("k256", 1024, synth.SEED),
         "p256": config_fixture("p256", 128, synth.SEED),
