@@ -22,6 +22,8 @@ def lib():
         L.eco_synth_scalars.argtypes = [i, u64, u64, vp, sz]
         L.eco_synth_points.argtypes = [i, u64, u64, vp, sz]
         L.eco_point_op.argtypes = [i, i, vp, vp, vp, sz]
+        L.eco_ecdsa_verify_batch.argtypes = [i, vp, vp, vp, vp, sz, i]
+        L.eco_ecdsa_sign_batch.argtypes = [i, vp, vp, vp, vp, vp, vp, sz, i]
         _LIB = L
     return _LIB
 
@@ -71,3 +73,23 @@ def point_op(curve, op, p, q=None):
     out = np.zeros_like(p)
     assert lib().eco_point_op(curve, op, _p(p), _p(q), _p(out), p.shape[0]) == 0
     return out
+
+
+def ecdsa_verify_batch(curve, prehash, sig_rs, pubkeys_xy, low_s=False):
+    z = np.ascontiguousarray(prehash, dtype=np.uint8).reshape(-1, nb(curve))
+    sg = np.ascontiguousarray(sig_rs, dtype=np.uint8).reshape(-1, 2 * nb(curve))
+    q = np.ascontiguousarray(pubkeys_xy, dtype=np.uint8).reshape(-1, 2 * nb(curve))
+    ok = np.zeros(z.shape[0], dtype=np.uint8)
+    assert lib().eco_ecdsa_verify_batch(curve, _p(z), _p(sg), _p(q), _p(ok), z.shape[0], int(low_s)) == 0
+    return ok
+
+
+def ecdsa_sign_batch(curve, d, k, prehash, low_s=False):
+    d = np.ascontiguousarray(d, dtype=np.uint8).reshape(-1, nb(curve))
+    k = np.ascontiguousarray(k, dtype=np.uint8).reshape(-1, nb(curve))
+    z = np.ascontiguousarray(prehash, dtype=np.uint8).reshape(-1, nb(curve))
+    sig = np.zeros((d.shape[0], 2 * nb(curve)), dtype=np.uint8)
+    rec = np.zeros(d.shape[0], dtype=np.uint8)
+    ok = np.zeros(d.shape[0], dtype=np.uint8)
+    assert lib().eco_ecdsa_sign_batch(curve, _p(d), _p(k), _p(z), _p(sig), _p(rec), _p(ok), d.shape[0], int(low_s)) == 0
+    return sig, rec, ok

@@ -364,8 +364,8 @@ static k256_pt k256_table_select(const k256_table* t, int8_t x) { /* mul.rs:92-1
   return r;
 }
 static k256_pt k256_lincomb(const k256_pt* xs, const sc4* ks, int nterms) { /* mul.rs:342-393 */
-  k256_table* tables = (k256_table*)malloc(sizeof(k256_table) * 2 * nterms);
-  int8_t* digits = (int8_t*)malloc(33 * 2 * nterms);
+  k256_table* tables = (k256_table*)malloc(sizeof(k256_table) * 2 * (size_t)nterms);
+  int8_t* digits = (int8_t*)malloc((size_t)66 * (size_t)nterms);
   for (int i = 0; i < nterms; i++) {
     sc4 r1, r2;
     k256_decompose(&ks[i], &r1, &r2);
@@ -818,7 +818,7 @@ int eco_synth_points(int curve, u64 seed, u64 first, u8* out_xy, size_t n) {
         mfe_mul(c, &rhs, &x, &x); mfe_mul(c, &rhs, &rhs, &x);
         mfe_add(c, &t3, &x, &x); mfe_add(c, &three, &t3, &x);  /* 3x */
         mfe_sub(c, &rhs, &rhs, &three);
-        mfe B; memset(&B, 0, sizeof(B)); memcpy(B.w, c->b, 8 * c->nl);
+        mfe B; memset(&B, 0, sizeof(B)); memcpy(B.w, c->b, sizeof(u64) * (size_t)c->nl);
         mfe_add(c, &rhs, &rhs, &B);
         /* (p+1)/4 */
         memcpy(e, c->p, sizeof(e));
@@ -834,6 +834,139 @@ int eco_synth_points(int curve, u64 seed, u64 first, u8* out_xy, size_t n) {
         break;
       }
     }
+  }
+  return 0;
+}
+
+/* ======================================================================================== */
+/* ECDSA (external ecdsa 0.16.9 hazmat::{verify_prehashed, sign_prehashed}, entered from        */
+/* k256/src/ecdsa.rs:182-209, p256/src/ecdsa.rs:72-75, p384/src/ecdsa.rs:69-72)                */
+/* ======================================================================================== */
+/* scalar fields: the generic Montgomery code above with the group order as modulus */
+static mcurve ORD[3];
+static pthread_once_t ord_once = PTHREAD_ONCE_INIT;
+static void ord_init_one(mcurve* c, int nl, const char* n) {
+  memset(c, 0, sizeof(*c));
+  c->nl = nl; c->nbytes = nl * 8;
+  hex_to_words(c->p, nl, n);
+  u64 inv = 1;
+  for (int i = 0; i < 6; i++) inv *= 2 - c->p[0] * inv;
+  c->minv = (u64)0 - inv;
+  mfe x; memset(&x, 0, sizeof(x)); x.w[0] = 1;
+  for (int i = 0; i < 64 * nl; i++) mfe_add(c, &x, &x, &x);
+  memcpy(c->one, x.w, sizeof(u64) * nl);
+  for (int i = 0; i < 64 * nl; i++) mfe_add(c, &x, &x, &x);
+  memcpy(c->r2, x.w, sizeof(u64) * nl);
+}
+static void ord_init(void) {
+  ord_init_one(&ORD[0], 4, "fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141");
+  ord_init_one(&ORD[1], 4, "ffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551");
+  ord_init_one(&ORD[2], 6, "ffffffffffffffffffffffffffffffffffffffffffffffffc7634d81f4372ddf581a0db248b0a77aecec196accc52973");
+}
+static int be_is_zero(const u8* a, int n) { int z = 1; for (int i = 0; i < n; i++) z &= (a[i] == 0); return z; }
+/* Reduce::reduce_bytes for a value < 2n */
+static void be_reduce_once(u8* a, const u8* n, int nb) { if (be_geq(a, n, nb)) be_sub(a, n, nb); }
+/* s > (n - 1) / 2  <=>  2 s > n */
+static int be_is_high(const u8* s, const u8* n, int nb) {
+  u8 t[49]; int carry = 0;
+  for (int i = nb - 1; i >= 0; i--) { int v = 2 * s[i] + carry; t[i + 1] = (u8)v; carry = v >> 8; }
+  t[0] = (u8)carry;
+  if (t[0]) return 1;
+  return memcmp(t + 1, n, nb) > 0;
+}
+static int pubkey_ok(int curve, const u8* xy, const u8* pmod, int nb) {
+  if (be_geq(xy, pmod, nb) || be_geq(xy + nb, pmod, nb)) return 0;
+  if (be_is_zero(xy, 2 * nb)) return 0;
+  if (curve == 0) {
+    fe5 x, y; fe5_from_bytes(&x, xy); fe5_from_bytes(&y, xy + 32);
+    fe5 l = fe5_sqr(&y), r = fe5_sqr(&x); r = fe5_mul(&r, &x);
+    fe5 seven = {{7, 0, 0, 0, 0}}; r = fe5_add(&r, &seven);
+    fe5 nr = fe5_negate(&r, 1); l = fe5_add(&l, &nr);
+    return fe5_normalizes_to_zero(&l);
+  }
+  const mcurve* c = get_mcurve(curve);
+  mfe x, y, l, r, t, three; mfe_from_bytes(c, &x, xy); mfe_from_bytes(c, &y, xy + nb);
+  MUL(l, y, y); MUL(r, x, x); MUL(r, r, x);
+  ADD(three, x, x); ADD(three, three, x); SUB(r, r, three);
+  memcpy(t.w, c->b, sizeof(t.w)); ADD(r, r, t); SUB(l, l, r);
+  return mfe_is_zero(c, &l);
+}
+/* R = u1 G + u2 Q -> affine x || y || inf, by the reference's lincomb */
+static void ecdsa_lincomb(int curve, const u8* u1, const u8* u2, const u8* q, u8* out) {
+  const int nb = curve == 2 ? 48 : 32;
+  if (curve == 0) {
+    sc4 ks[2]; k256_pt ps[2];
+    sc4_from_bytes(&ks[0], u1); sc4_from_bytes(&ks[1], u2);
+    u8 g[64]; memcpy(g, K256_GX, 32); memcpy(g + 32, K256_GY, 32);
+    ps[0] = k256_pt_from_affine_bytes(g); ps[1] = k256_pt_from_affine_bytes(q);
+    k256_pt r = k256_lincomb(ps, ks, 2);
+    k256_to_affine_bytes(out, &r);
+  } else {
+    const mcurve* c = get_mcurve(curve);
+    mpt g; memset(&g, 0, sizeof(g)); memcpy(g.x.w, c->gx, 8 * c->nl); memcpy(g.y.w, c->gy, 8 * c->nl); memcpy(g.z.w, c->one, 8 * c->nl);
+    mpt qq = mpt_from_affine_bytes(c, q);
+    mpt a = mpt_mul(c, &g, u1), b = mpt_mul(c, &qq, u2);
+    a = mpt_add(c, &a, &b);
+    mpt_to_affine_bytes(c, out, &a);
+  }
+  (void)nb;
+}
+/* z: bits2field output, sig: r || s, q: x || y; ok[i] in {0, 1}.  low_s: k256's VerifyPrimitive rejects s > n/2. */
+int eco_ecdsa_verify_batch(int curve, const u8* z, const u8* sig, const u8* q, u8* ok, size_t n, int low_s) {
+  if (curve < 0 || curve > 2) return -1;
+  pthread_once(&ord_once, ord_init);
+  const mcurve* f = &ORD[curve];
+  u8 pm[48], nm[48]; int nb;
+  curve_moduli(curve, pm, nm, &nb);
+  for (size_t i = 0; i < n; i++) {
+    const u8 *r = sig + 2 * nb * i, *s = r + nb;
+    ok[i] = 0;
+    if (be_is_zero(r, nb) || be_is_zero(s, nb) || be_geq(r, nm, nb) || be_geq(s, nm, nb)) continue;
+    if (low_s && be_is_high(s, nm, nb)) continue;
+    if (!pubkey_ok(curve, q + 2 * nb * i, pm, nb)) continue;
+    u8 e[48]; memcpy(e, z + nb * i, nb); be_reduce_once(e, nm, nb);
+    mfe sm, w, em, rm, u1m, u2m;
+    mfe_from_bytes(f, &sm, s); mfe_invert(f, &w, &sm);
+    mfe_from_bytes(f, &em, e); mfe_from_bytes(f, &rm, r);
+    mfe_mul(f, &u1m, &em, &w); mfe_mul(f, &u2m, &rm, &w);
+    u8 u1[48], u2[48], R[97];
+    mfe_to_bytes(f, u1, &u1m); mfe_to_bytes(f, u2, &u2m);
+    ecdsa_lincomb(curve, u1, u2, q + 2 * nb * i, R);
+    if (R[2 * nb]) continue;
+    be_reduce_once(R, nm, nb);
+    ok[i] = memcmp(R, r, nb) == 0;
+  }
+  return 0;
+}
+/* sig_out: r || s (zeros when ok = 0); recid: y_is_odd | x_reduced << 1 */
+int eco_ecdsa_sign_batch(int curve, const u8* d, const u8* k, const u8* z, u8* sig_out, u8* recid, u8* ok, size_t n, int low_s) {
+  if (curve < 0 || curve > 2) return -1;
+  pthread_once(&ord_once, ord_init);
+  if (curve == 0) pthread_once(&k256_gen_once, k256_gen_init);
+  const mcurve* f = &ORD[curve];
+  u8 pm[48], nm[48]; int nb;
+  curve_moduli(curve, pm, nm, &nb);
+  for (size_t i = 0; i < n; i++) {
+    const u8 *di = d + nb * i, *ki = k + nb * i;
+    u8* o = sig_out + 2 * nb * i;
+    memset(o, 0, 2 * nb); ok[i] = 0; if (recid) recid[i] = 0;
+    if (be_is_zero(di, nb) || be_is_zero(ki, nb) || be_geq(di, nm, nb) || be_geq(ki, nm, nb)) continue;
+    u8 R[97];
+    job_t j = {curve, 0, 1, ki, NULL, R, 0, 1, 0};
+    do_mul_range(&j);
+    int y_odd = R[2 * nb - 1] & 1, x_red = be_geq(R, nm, nb);
+    be_reduce_once(R, nm, nb);
+    u8 e[48]; memcpy(e, z + nb * i, nb); be_reduce_once(e, nm, nb);
+    mfe km, kinv, em, rm, dm, t, sm;
+    mfe_from_bytes(f, &km, ki); mfe_invert(f, &kinv, &km);
+    mfe_from_bytes(f, &em, e); mfe_from_bytes(f, &rm, R); mfe_from_bytes(f, &dm, di);
+    mfe_mul(f, &t, &rm, &dm); mfe_add(f, &t, &t, &em); mfe_mul(f, &sm, &t, &kinv);
+    u8 sb[48]; mfe_to_bytes(f, sb, &sm);
+    if (be_is_zero(R, nb) || be_is_zero(sb, nb)) continue;
+    if (low_s && be_is_high(sb, nm, nb)) { u8 t2[48]; memcpy(t2, nm, nb); be_sub(t2, sb, nb); memcpy(sb, t2, nb); y_odd ^= 1; }
+    memcpy(o, R, nb); memcpy(o + nb, sb, nb);
+    if (recid) recid[i] = (u8)(y_odd | (x_red << 1));
+    ok[i] = 1;
   }
   return 0;
 }

@@ -59,3 +59,39 @@ def test_wycheproof(cn):
         assert got == bool(ok), f"row {i}"
         n_pass += got
     assert n_pass > 100
+
+
+@pytest.mark.parametrize("cn", ["k256", "p256", "p384"])
+def test_c_oracle_matches_model_and_vectors(cn, ref_vectors):
+    """oracle/ecoracle.c's ECDSA (the cpu_baseline of the ECDSA bench workloads) against the KATs, the
+    Wycheproof flags and the big-integer model on corrupted inputs."""
+    import numpy as np
+    from oracle import coracle as CO
+    c = M.CURVES[cn]
+    cid = M.CURVE_IDS[cn]
+    nb = c.nbytes
+    tob = lambda v: v.to_bytes(nb, "big")
+    vs = ref_vectors[cn]["ecdsa"]
+    d = np.frombuffer(b"".join(bytes.fromhex(v["d"]) for v in vs), dtype=np.uint8)
+    k = np.frombuffer(b"".join(bytes.fromhex(v["k"]) for v in vs), dtype=np.uint8)
+    z = np.frombuffer(b"".join(M.bits2field(c, bytes.fromhex(v["m"])) for v in vs), dtype=np.uint8)
+    sig, rec, ok = CO.ecdsa_sign_batch(cid, d, k, z)
+    assert ok.all()
+    for i, v in enumerate(vs):
+        assert bytes(sig[i]).hex() == v["r"] + v["s"]
+    rows = wycheproof(cn)
+    zs, sgs, qs, want = [], [], [], []
+    for wx, wy, msg, sg, flag in rows:
+        rs = der.decode_signature(bytes.fromhex(sg), nb)
+        if rs is None:
+            continue
+        r, s = rs
+        if cn == "k256" and c.n // 2 < s < c.n:
+            s = c.n - s
+        zs.append(M.bits2field(c, HASH[cn](bytes.fromhex(msg)).digest()))
+        sgs.append(tob(r) + tob(s))
+        qs.append(tob(padded(c, wx)) + tob(padded(c, wy)))
+        want.append(flag)
+    got = CO.ecdsa_verify_batch(cid, np.frombuffer(b"".join(zs), dtype=np.uint8), np.frombuffer(b"".join(sgs), dtype=np.uint8),
+                                np.frombuffer(b"".join(qs), dtype=np.uint8), low_s=(cn == "k256"))
+    assert list(got) == want

@@ -31,6 +31,23 @@ if mode == "lincomb2":
         ms = ctx.timer_stop()
         print(f"{cn} lincomb2 {'ref' if flags else 'default'}: n=2^{lg} {ms:.2f} ms  {n/ms*1e3/1e6:.3f} M lincombs/s", flush=True)
     sys.exit(0)
+if mode == "ecdsa":
+    # sign n prehashes on the device, then time verification of the valid batch
+    d_k = torch.empty((n, nb), dtype=torch.uint8, device="cuda"); d_z = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_k, n, synth.SEED, n); cv.synth_scalars_device(d_z, n, synth.SEED, 2 * n)
+    d_sig = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda"); d_rec = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    cv.mul_device(d_s, None, d_p, n)
+    for rep in range(3):
+        ctx.timer_start()
+        cv.ecdsa_sign_device(d_s, d_k, d_z, d_sig, d_rec, d_i, n)
+        ms = ctx.timer_stop()
+        print(f"{cn} ecdsa sign: n=2^{lg} {ms:.2f} ms  {n/ms*1e3/1e6:.3f} M signatures/s", flush=True)
+    for rep in range(3):
+        ctx.timer_start()
+        cv.ecdsa_verify_device(d_z, d_sig, d_p, d_i, n)
+        ms = ctx.timer_stop()
+        print(f"{cn} ecdsa verify: n=2^{lg} {ms:.2f} ms  {n/ms*1e3/1e6:.3f} M verifications/s  all_ok={bool(d_i.all())}", flush=True)
+    sys.exit(0)
 if mode == "msm":
     cv.synth_points_device(d_p, n, synth.SEED); ctx.synchronize()
     d_r = torch.empty((64,), dtype=torch.uint8, device="cuda")
