@@ -67,6 +67,15 @@ WORKLOADS = {
                            # 16 signed 16-bit windows: one mixed addition (8M+3S) per term per window; bucket reduction amortised
                            modmul=16 * 11, mac=64, bytes_per_unit=32 + 64, kernel="msm::bucket_sum_kernel (+ digits/scan/scatter/reduce)",
                            desc="k256 multi-scalar multiplication, 2^%d terms per GPU (one sum; ranks exchange one point each), affine output"),
+    # ECDSA verification: prep (scalar field) -> u1 G (16-bit fixed-base table) -> u2 Q (the headline
+    # kernel) -> inversion-free check.  Field modmuls: 1764 + 230 + 7; scalar-field work (27 dense Montgomery products of
+    # 136 MACs per signature) is folded in as 57 modmul equivalents.
+    "k256_ecdsa_verify": dict(curve="k256", cid=0, log2n=22, fixed=False, msm=False, ecdsa=True, metric="k256 ECDSA verifications/sec", unit="verifications/s",
+                           modmul=1764 + 230 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul16_kernel + k256_mul_fast_kernel<16,4> + verify_check",
+                           desc="k256 ECDSA verify_prehashed (low-s rule), 2^%d independent (prehash, signature, public key) triples per GPU"),
+    "p256_ecdsa_verify": dict(curve="p256", cid=1, log2n=22, fixed=False, msm=False, ecdsa=True, metric="p256 ECDSA verifications/sec", unit="verifications/s",
+                           modmul=3160 + 230 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul16_kernel + vb::mul_kernel<CurveP256,8,3> + verify_check",
+                           desc="p256 ECDSA verify_prehashed, 2^%d independent (prehash, signature, public key) triples per GPU"),
 }
 # v_mad_u64_u32 issues at half the FP32-FMA rate on gfx950 (measured, tools/ubench/valu_rates.hip):
 # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz
@@ -74,9 +83,33 @@ PEAK_TMACS = 256 * 4 * 16 * 2.4e9 / 1e12
 PEAK_HBM_GBS = 8000.0
 
 
+ECDSA_CORRUPT_EVERY = 7     # every 7th signature of the synthetic ECDSA batch has one bit of s flipped (must be rejected)
+
+
+def cpu_ecdsa_worker(args):
+    """ECDSA workload in a forked child: inputs made with the C oracle (untimed), verification timed."""
+    first, n, cid = args
+    import numpy as np
+    from oracle import coracle as CO
+    d = CO.synth_scalars(cid, n, SEED, first)
+    k = CO.synth_scalars(cid, n, SEED + 1, first)
+    z = CO.synth_scalars(cid, n, SEED + 2, first)
+    low_s = (cid == 0)
+    sig, rec, ok = CO.ecdsa_sign_batch(cid, d, k, z, low_s=low_s)
+    q = CO.lincomb_batch(cid, d, None, threads=1)[:, :-1].copy()
+    idx = np.arange(first, first + n)
+    sig[idx % ECDSA_CORRUPT_EVERY == 0, -1] ^= 1
+    t0 = time.perf_counter()
+    v = CO.ecdsa_verify_batch(cid, z, sig, q, low_s=low_s)
+    dt = time.perf_counter() - t0
+    return first, n, dt, sig.tobytes() + v.tobytes()
+
+
 def cpu_baseline_worker(args):
     """Runs in a forked child BEFORE the parent touches the GPU: C oracle on a slice."""
     first, n, cid, fixed, msm = args
+    if msm == "ecdsa":
+        return cpu_ecdsa_worker((first, n, cid))
     from oracle import coracle as CO
     s = CO.synth_scalars(cid, n, SEED, first)
     p = None if fixed else CO.synth_points(cid, n, SEED, first)
@@ -101,7 +134,7 @@ def run_cpu_baseline(sample, procs, cid=0, fixed=False, msm=False):
     wall = time.perf_counter() - t0
     busy = max(r[2] for r in res)      # slowest worker, excludes process start-up and input synthesis
     outs = b"".join(r[3] for r in sorted(res))
-    return {"wall_s": wall, "busy_s": busy, "out": outs, "procs": len(jobs)}
+    return {"wall_s": wall, "busy_s": busy, "out": outs, "procs": len(jobs), "parts": [(r[0], r[1], r[3]) for r in sorted(res)]}
 
 
 def main():
@@ -135,7 +168,10 @@ def main():
         # time on 16 cores); --cpu-sample overrides
         per_proc = {"k256": 65536, "p256": 8192, "p384": 4096}[wl["curve"]] // (1 if not wl["fixed"] or wl["curve"] != "k256" else 1)
         sample = args.cpu_sample or min(n, per_proc * procs)
-        cpu = run_cpu_baseline(sample, procs, wl["cid"], wl["fixed"], wl["msm"])
+        if wl.get("ecdsa"):
+            per_proc //= 2                  # a verification is two scalar multiplications on the CPU
+            sample = args.cpu_sample or min(n, per_proc * procs)
+        cpu = run_cpu_baseline(sample, procs, wl["cid"], wl["fixed"], "ecdsa" if wl.get("ecdsa") else wl["msm"])
         cpu["sample"] = sample
 
     import numpy as np
@@ -172,11 +208,26 @@ def main():
     cv.synth_scalars_device(d_s, n, SEED, first)
     if d_p is not None:
         cv.synth_points_device(d_p, n, SEED, first)
+    if wl.get("ecdsa"):
+        # d_s = secret keys; nonces and prehashes from two more seeded streams; public keys and signatures are made on
+        # the device (fixed-base kernel, sign pipeline) before the timed region; d_p holds the public keys
+        d_k = torch.empty((n, nb), dtype=torch.uint8, device=dev)
+        d_z = torch.empty((n, nb), dtype=torch.uint8, device=dev)
+        d_sig = torch.empty((n, 2 * nb), dtype=torch.uint8, device=dev)
+        cv.synth_scalars_device(d_k, n, SEED + 1, first)
+        cv.synth_scalars_device(d_z, n, SEED + 2, first)
+        cv.mul_device(d_s, None, d_p, n)
+        cv.ecdsa_sign_device(d_s, d_k, d_z, d_sig, None, d_i, n)
+        ctx.synchronize()
+        bad = (torch.arange(first, first + n, device=dev) % ECDSA_CORRUPT_EVERY) == 0
+        d_sig[bad, -1] ^= 1
     torch.cuda.synchronize()
     msm_result = {}
 
     def step():
-        if wl["msm"]:
+        if wl.get("ecdsa"):
+            cv.ecdsa_verify_device(d_z, d_sig, d_p, d_i, n)
+        elif wl["msm"]:
             if dist is None:
                 cv.msm_device(d_s, d_p, n, d_o)
             else:
@@ -218,7 +269,15 @@ def main():
     parity = None
     if cpu is not None:
         m = cpu["sample"]
-        if wl["msm"]:
+        if wl.get("ecdsa"):
+            # signatures made on the device and accept/reject flags, against the C oracle's for the same indices
+            g_sig, g_ok = d_sig[:m].cpu().numpy(), d_i[:m].cpu().numpy()
+            parity = True
+            for lo, cnt, blob in cpu["parts"]:
+                parity &= (g_sig[lo:lo + cnt].tobytes() == blob[:cnt * 2 * nb]) and (g_ok[lo:lo + cnt].tobytes() == blob[cnt * 2 * nb:])
+            want_ok = (np.arange(m) % ECDSA_CORRUPT_EVERY != 0)
+            parity &= bool((g_ok.astype(bool) == want_ok).all())
+        elif wl["msm"]:
             # the oracle computed k_i * P_i for the first m terms (projective); fold them with the oracle's
             # complete addition and compare with the GPU MSM over the same m terms
             from oracle import coracle as CO
