@@ -315,7 +315,7 @@ def main():
         alg_bytes = n * wl["bytes_per_unit"]
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.workload == "k256_varbase" and args.schedule == "fast" and args.log2n == 24:
             try:
                 with open(pmc) as f:
                     traffic = json.load(f).get("hbm_bytes_per_launch")
