@@ -30,7 +30,18 @@ extern "C" {
     pub fn ecgpu_batch_normalize(
         ctx: *mut ecgpu_ctx, curve: c_int, p_xyz: *const u8, out_xy: *mut u8, out_inf: *mut u8, n: usize, mem: c_int,
     ) -> c_int;
+    pub fn ecgpu_ecdsa_verify_batch(
+        ctx: *mut ecgpu_ctx, curve: c_int, prehash: *const u8, sig_rs: *const u8, pubkeys_xy: *const u8, ok: *mut u8,
+        n: usize, mem: c_int, flags: c_uint,
+    ) -> c_int;
+    pub fn ecgpu_ecdsa_sign_batch(
+        ctx: *mut ecgpu_ctx, curve: c_int, secret_d: *const u8, nonce_k: *const u8, prehash: *const u8, sig_rs: *mut u8,
+        recovery_id: *mut u8, ok: *mut u8, n: usize, mem: c_int, flags: c_uint,
+    ) -> c_int;
 }
+
+/// `ECGPU_ECDSA_LOW_S`: the k256 rules of k256/src/ecdsa.rs:182-207.
+pub const ECGPU_ECDSA_LOW_S: c_uint = 2;
 
 pub struct Gpu(*mut ecgpu_ctx);
 
