@@ -156,6 +156,16 @@ int ecgpu_validate_points(ecgpu_ctx* ctx, int curve, const uint8_t* points_xy, u
 int ecgpu_decompress_batch(ecgpu_ctx* ctx, int curve, const uint8_t* x, const uint8_t* y_is_odd,
                            uint8_t* out_xy, uint8_t* ok, size_t n, int mem);
 
+/* GroupEncoding::to_bytes / from_bytes (k256 affine.rs:213-238, primeorder affine.rs:256-278): the fixed-width
+ * compressed SEC1 form, 1 + field_bytes bytes per point: 0x02 | 0x03 then x; the identity is all zeros.
+ * to_bytes takes affine or projective points (projective input is batch-normalised on the device);
+ * from_bytes gives out_xy (zeros for the identity) and ok[i] = 0 for a bad tag, x >= p or no root; like the
+ * reference it also accepts tag 0x05 (compact: the even root). */
+int ecgpu_to_bytes_batch(ecgpu_ctx* ctx, int curve, const uint8_t* points, int point_format, uint8_t* out,
+                         size_t n, int mem);
+int ecgpu_from_bytes_batch(ecgpu_ctx* ctx, int curve, const uint8_t* in, uint8_t* out_xy, uint8_t* ok,
+                           size_t n, int mem);
+
 /* ---- ECDSA over the path (the callers of mul_by_generator / lincomb) ---------------------------
  * VerifyPrimitive::verify_prehashed / SignPrimitive::try_sign_prehashed; the primitives are the
  * external ecdsa 0.16.9 hazmat functions entered from k256/src/ecdsa.rs:182-209,

@@ -646,3 +646,28 @@ def ecdsa_sign_prehashed(c: Curve, d: int, k: int, z: bytes, normalize_s: bool =
         s = n - s
         y_odd ^= 1
     return r, s, y_odd | (x_reduced << 1)
+
+
+# --- GroupEncoding::{to_bytes, from_bytes}: fixed-width compressed SEC1 (k256 affine.rs:213-238, primeorder affine.rs:256-278)
+
+def group_to_bytes(c: Curve, A) -> bytes:
+    """A = (x, y) or None for the identity -> 1 + nbytes bytes."""
+    if A is None:
+        return bytes(c.nbytes + 1)
+    return bytes([2 + (A[1] & 1)]) + A[0].to_bytes(c.nbytes, "big")
+
+
+def group_from_bytes(c: Curve, b: bytes):
+    """-> (ok, point) with point = (x, y) or None for the identity."""
+    tag, x = b[0], int.from_bytes(b[1:], "big")
+    if tag in (2, 3, 5):
+        got = decompress(c, x, 1 if tag == 3 else 0)
+        if got is None:
+            return False, None
+        px, py = got
+        if tag == 5 and c.name != "k256":          # primeorder decompact: the smaller of y and -y (affine.rs:66-77)
+            py = min(py, c.p - py)
+        return True, (px, py)
+    if not any(b):
+        return True, None
+    return False, None

@@ -5,6 +5,7 @@
 #include "kernels.hpp"
 #include "fixedbase.hpp"
 #include "ecdsa_kernels.hpp"
+#include "sec1_kernels.hpp"
 
 namespace ecgpu {
 
@@ -154,6 +155,28 @@ struct CurveOps {
     HIPCHK(c, hipGetLastError());
     return 0;
   }
+  // GroupEncoding::to_bytes of affine or projective points (projective input is batch-normalised first)
+  static int to_bytes(ecgpu_ctx* c, const u32* pts, int pt_fmt, uint8_t* out, size_t n) {
+    const u32* xy = pts;
+    const uint8_t* inf = nullptr;
+    if (pt_fmt == FMT_PROJECTIVE) {
+      const size_t sz_p = al256(n * 2 * C::NB);
+      int rc = ecdsa_reserve(c, sz_p + al256(n));
+      if (rc) return rc;
+      u32* t = (u32*)c->ecdsa_ws;
+      uint8_t* ti = (uint8_t*)c->ecdsa_ws + sz_p;
+      if ((rc = normalize(c, pts, t, ti, n))) return rc;
+      xy = t; inf = ti;
+    }
+    hipLaunchKernelGGL((sec1::to_bytes_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, xy, inf, out, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static int from_bytes(ecgpu_ctx* c, const uint8_t* in, u32* out_xy, uint8_t* ok, size_t n) {
+    hipLaunchKernelGGL((sec1::from_bytes_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, in, out_xy, ok, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   // ECDSA pipelines (ecdsa_kernels.hpp): the scalar multiplications run on the throughput kernels above
   static int ecdsa_reserve(ecgpu_ctx* c, size_t need) {
     if (need <= c->ecdsa_ws_cap) return 0;
@@ -199,7 +222,7 @@ struct CurveOps {
   }
   static const ecgpu_curve_ops* table() {
     static const ecgpu_curve_ops t = {field_op, point_op, normalize, lincomb, msm, validate_scalars, validate_points,
-                                      decompress, synth_scalars, synth_points, ecdsa_verify, ecdsa_sign};
+                                      decompress, synth_scalars, synth_points, to_bytes, from_bytes, ecdsa_verify, ecdsa_sign};
     return &t;
   }
 };

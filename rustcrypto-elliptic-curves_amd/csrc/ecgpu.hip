@@ -285,6 +285,34 @@ int ecgpu_decompress_batch(ecgpu_ctx* c, int curve, const uint8_t* x, const uint
   return finish_host(c, mem);
 }
 
+int ecgpu_to_bytes_batch(ecgpu_ctx* c, int curve, const uint8_t* points, int pt_fmt, uint8_t* out, size_t n, int mem) {
+  if (!c || !points || !out) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (pt_fmt != ECGPU_PT_AFFINE && pt_fmt != ECGPU_PT_PROJECTIVE) return ecgpu_set_err(c, ECGPU_ERR_ARG, "bad point format");
+  if (n == 0) return ECGPU_OK;
+  ENTER(c, curve);
+  Buf bp, bo;
+  int rc;
+  if ((rc = buf_in(c, bp, 0, points, n * (pt_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb, mem))) return rc;
+  if ((rc = buf_out(c, bo, 2, out, n * (nb + 1), mem))) return rc;
+  if ((rc = ops->to_bytes(c, (const uint32_t*)bp.dev, pt_fmt, (uint8_t*)bo.dev, n))) return rc;
+  if ((rc = buf_finish(c, bo))) return rc;
+  return finish_host(c, mem);
+}
+int ecgpu_from_bytes_batch(ecgpu_ctx* c, int curve, const uint8_t* in, uint8_t* out_xy, uint8_t* ok, size_t n, int mem) {
+  if (!c || !in || !out_xy || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (n == 0) return ECGPU_OK;
+  ENTER(c, curve);
+  Buf bi, bo, bk;
+  int rc;
+  if ((rc = buf_in(c, bi, 0, in, n * (nb + 1), mem))) return rc;
+  if ((rc = buf_out(c, bo, 2, out_xy, n * 2 * nb, mem))) return rc;
+  if ((rc = buf_out(c, bk, 3, ok, n, mem))) return rc;
+  if ((rc = ops->from_bytes(c, (const uint8_t*)bi.dev, (uint32_t*)bo.dev, (uint8_t*)bk.dev, n))) return rc;
+  if ((rc = buf_finish(c, bo))) return rc;
+  if ((rc = buf_finish(c, bk))) return rc;
+  return finish_host(c, mem);
+}
+
 // ---------------------------------------------------------------------------------------------
 int ecgpu_ecdsa_verify_batch(ecgpu_ctx* c, int curve, const uint8_t* prehash, const uint8_t* sig_rs, const uint8_t* pubkeys_xy, uint8_t* ok,
                              size_t n, int mem, unsigned flags) {

@@ -1,0 +1,79 @@
+// GroupEncoding::{to_bytes, from_bytes} for batches: the fixed-width compressed SEC1 representation
+// (1 + NB bytes: tag 0x02 / 0x03 and x; the identity is all zeros - "technically an invalid SEC1 encoding",
+// k256/src/arithmetic/affine.rs:213-238, primeorder/src/affine.rs:256-278).  Device code only.
+#pragma once
+#include "kernels.hpp"
+
+namespace ecgpu {
+namespace sec1 {
+
+// affine x || y (zeros = identity) -> tag || x
+template <class C>
+__global__ void __launch_bounds__(256) to_bytes_kernel(const u32* xy, const uint8_t* inf, uint8_t* out, size_t n) {
+  constexpr int NB = C::NB;
+  ECGPU_GRID_STRIDE(i, n) {
+    const uint8_t* src = (const uint8_t*)(xy + i * 2 * C::NW);
+    uint8_t* o = out + i * (NB + 1);
+    u32 z = 0;
+#pragma unroll
+    for (int j = 0; j < 2 * C::NW; j++) z |= xy[i * 2 * C::NW + j];
+    const bool id = (z == 0) || (inf && inf[i]);
+    o[0] = id ? 0 : (uint8_t)(2 + (src[2 * NB - 1] & 1));
+    for (int j = 0; j < NB; j++) o[1 + j] = id ? 0 : src[j];
+  }
+}
+
+// tag || x -> affine x || y, ok.  Accepted: 0x02 / 0x03 (compressed), 0x05 (compact: the even root, what
+// EncodedPoint::from_bytes makes of a 1 + NB byte string with that tag), all zeros (identity).
+template <class C>
+__global__ void __launch_bounds__(256) from_bytes_kernel(const uint8_t* in, u32* out_xy, uint8_t* ok, size_t n) {
+  constexpr int NB = C::NB, NW = C::NW;
+  ECGPU_GRID_STRIDE(i, n) {
+    const uint8_t* s = in + i * (NB + 1);
+    const uint8_t tag = s[0];
+    u32 raw[NW], any = 0;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      raw[j] = (u32)s[1 + 4 * j] | ((u32)s[2 + 4 * j] << 8) | ((u32)s[3 + 4 * j] << 16) | ((u32)s[4 + 4 * j] << 24);
+      any |= raw[j];
+    }
+    u32* o = out_xy + i * 2 * NW;
+    const bool tagged = (tag == 2 || tag == 3 || tag == 5);
+    bool good = false;
+    typename C::Fe x, y, zero;
+    C::fe_zero(zero);
+    x = zero; y = zero;
+    if (tagged) {
+      u32 lx[NW], p[NW];
+      words_load_be<NW>(lx, raw);
+      C::modulus(p);
+      const bool canon = !mp_geq<NW>(lx, p);
+      typename C::Fe rhs, ny;
+      C::fe_load(x, raw);
+      C::curve_rhs(rhs, x);
+      const bool has = C::fe_sqrt(y, rhs);
+      C::fe_neg(ny, y);
+      const bool odd = C::fe_is_odd(y);
+      bool keep = (odd == (tag == 3));
+      if (tag == 5 && !C::A_IS_ZERO) {
+        // primeorder's decompact takes the numerically smaller of y and -y (primeorder/src/affine.rs:66-77,157-159);
+        // k256's takes the even root (k256/src/arithmetic/affine.rs:207-211)
+        u32 yb[NW], nb_[NW], yl[NW], nl[NW];
+        C::fe_store(yb, y); C::fe_store(nb_, ny);
+        words_load_be<NW>(yl, yb); words_load_be<NW>(nl, nb_);
+        keep = mp_geq<NW>(nl, yl);
+      }
+      C::fe_select(y, keep, y, ny);
+      good = canon && has;
+      if (!good) { x = zero; y = zero; }
+    } else if (tag == 0 && any == 0) {
+      good = true;                                  // the fixed-width identity
+    }
+    C::fe_store(o, x);
+    C::fe_store(o + NW, y);
+    ok[i] = good ? 1 : 0;
+  }
+}
+
+}  // namespace sec1
+}  // namespace ecgpu

@@ -76,6 +76,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.ecgpu_validate_scalars.argtypes = [vp, i, u8p, u8p, sz, i]
     lib.ecgpu_validate_points.argtypes = [vp, i, u8p, u8p, sz, i]
     lib.ecgpu_decompress_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i]
+    lib.ecgpu_to_bytes_batch.argtypes = [vp, i, u8p, i, u8p, sz, i]
+    lib.ecgpu_from_bytes_batch.argtypes = [vp, i, u8p, u8p, u8p, sz, i]
     lib.ecgpu_ecdsa_verify_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
     lib.ecgpu_ecdsa_sign_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
     lib.ecgpu_synth_scalars.argtypes = [vp, i, ctypes.c_uint64, ctypes.c_uint64, u8p, sz]
@@ -97,6 +99,7 @@ EXPORTED_SYMBOLS = (
     "ecgpu_point_add_mixed_batch", "ecgpu_point_double_batch", "ecgpu_batch_normalize", "ecgpu_mul_batch",
     "ecgpu_lincomb_batch", "ecgpu_msm", "ecgpu_validate_scalars", "ecgpu_validate_points", "ecgpu_decompress_batch",
     "ecgpu_synth_scalars", "ecgpu_synth_points", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_sign_batch",
+    "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch",
 )
 
 
@@ -271,6 +274,19 @@ class Curve:
         odd = np.ascontiguousarray(y_is_odd, dtype=np.uint8)
         out, ok = _host_out(len(x), 2 * self.nb), np.zeros(len(x), dtype=np.uint8)
         self.ctx.check(self.ctx.lib.ecgpu_decompress_batch(self.ctx.handle, self.id, _ptr(x)[0], _ptr(odd)[0], _ptr(out)[0], _ptr(ok)[0], len(x), HOST))
+        return out, ok
+
+    # --- GroupEncoding::{to_bytes, from_bytes} ------------------------------------------------------
+    def to_bytes(self, points, point_format: int = AFFINE) -> np.ndarray:
+        p = _as_host(points, (3 if point_format == PROJECTIVE else 2) * self.nb)
+        out = _host_out(len(p), self.nb + 1)
+        self.ctx.check(self.ctx.lib.ecgpu_to_bytes_batch(self.ctx.handle, self.id, _ptr(p)[0], point_format, _ptr(out)[0], len(p), HOST))
+        return out
+
+    def from_bytes(self, encoded):
+        e = _as_host(encoded, self.nb + 1)
+        out, ok = _host_out(len(e), 2 * self.nb), np.zeros(len(e), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ecgpu_from_bytes_batch(self.ctx.handle, self.id, _ptr(e)[0], _ptr(out)[0], _ptr(ok)[0], len(e), HOST))
         return out, ok
 
     # --- ECDSA: VerifyPrimitive::verify_prehashed / SignPrimitive::try_sign_prehashed ------------------

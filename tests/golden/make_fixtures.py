@@ -103,6 +103,18 @@ def wycheproof_rows(curve):
             for i in range(0, len(items), 5)]
 
 
+def encoding_vectors(curve):
+    """SEC1 encodings of the base point held by the affine tests (k256/src/arithmetic/affine.rs:374-381,
+    p256/tests/affine.rs:12-31, p384/tests/affine.rs)."""
+    t = read(f"{curve}/src/arithmetic/affine.rs" if curve == "k256" else f"{curve}/tests/affine.rs")
+    out = {}
+    for name in ("UNCOMPRESSED_BASEPOINT", "COMPRESSED_BASEPOINT", "COMPACT_BASEPOINT", "UNCOMPACT_BASEPOINT"):
+        m = re.search(r"const %s: &\[u8\] =\s*&hex!\(\s*((?:\"[^\"]*\"\s*)+)\)" % name, t)
+        if m:
+            out[name.lower()] = re.sub(r"[^0-9A-Fa-f]", "", m.group(1)).lower()
+    return out
+
+
 def h2c_vectors(curve):
     t = read(f"{curve}/src/arithmetic/hash2curve.rs")
     i = t.index("const TEST_VECTORS")
@@ -147,7 +159,7 @@ def config_fixture(curve_name, n, seed):
 def main():
     fx = {}
     for c in ("k256", "p256", "p384"):
-        fx[c] = {"group": group_vectors(c), "ecdsa": ecdsa_vectors(c), "hash2curve": h2c_vectors(c)}
+        fx[c] = {"group": group_vectors(c), "ecdsa": ecdsa_vectors(c), "hash2curve": h2c_vectors(c), "encoding": encoding_vectors(c)}
     fx["k256"]["field_dbl"] = field_dbl("k256")
     fx["p256"]["field_dbl"] = field_dbl("p256")
     fx["k256"]["field_kat"] = risc0_field_kats()

@@ -230,3 +230,45 @@ def test_fixed_base_wide_table_path(ctx, cn, cid):
     want = CO.lincomb_batch(cid, s[idx].copy(), None, threads=4)
     got = np.concatenate([o[idx], inf[idx][:, None]], axis=1)
     assert bytes(got) == bytes(want)
+
+
+@pytest.mark.parametrize("cn", ["k256", "p256", "p384"])
+def test_group_encoding_to_from_bytes(ctx, cn, ref_vectors):
+    """GroupEncoding::{to_bytes, from_bytes} against the model: reference base-point vectors, random points (affine and
+    projective input), the identity, compact tag, bad tags, x >= p, x without a root."""
+    import random
+    c = M.CURVES[cn]
+    cv = ctx.curve(cn)
+    nb = c.nbytes
+    rng = random.Random(99)
+    pts = [None, (c.gx, c.gy)] + [M.affine_mul(c, rng.randrange(1, c.n), (c.gx, c.gy)) for _ in range(40)]
+    aff = b"".join(bytes(2 * nb) if P is None else M.i2b(c, P[0]) + M.i2b(c, P[1]) for P in pts)
+    want = [M.group_to_bytes(c, P) for P in pts]
+    got = cv.to_bytes(aff)
+    assert [bytes(g) for g in got] == want
+    assert want[1].hex() == ref_vectors[cn]["encoding"]["compressed_basepoint"]
+    proj = []
+    for P in pts:
+        if P is None:
+            proj.append(M.proj_bytes(c, M.IDENTITY))
+        else:
+            z = rng.randrange(1, c.p)
+            proj.append(M.proj_bytes(c, (P[0] * z % c.p, P[1] * z % c.p, z)))
+    got = cv.to_bytes(b"".join(proj), point_format=1)
+    assert [bytes(g) for g in got] == want
+    enc = list(want)
+    enc += [bytes([5]) + w[1:] for w in want[1:6]]                       # compact tag
+    enc += [bytes([4]) + want[1][1:], bytes([1]) + want[1][1:], bytes([0]) + want[1][1:], bytes([6]) + bytes(nb)]
+    enc += [bytes([2]) + M.i2b(c, c.p), bytes([3]) + (c.p + 5).to_bytes(nb, "big"), bytes([2]) + b"\xff" * nb]
+    x = 1
+    while M.decompress(c, x, 0) is not None:
+        x += 1
+    enc += [bytes([2]) + M.i2b(c, x)]                                    # no square root
+    if "compact_basepoint" in ref_vectors[cn]["encoding"]:
+        enc += [bytes.fromhex(ref_vectors[cn]["encoding"]["compact_basepoint"])]
+    out, ok = cv.from_bytes(b"".join(enc))
+    for i, e in enumerate(enc):
+        w_ok, P = M.group_from_bytes(c, e)
+        assert bool(ok[i]) == w_ok, (i, e.hex())
+        exp = bytes(2 * nb) if (P is None) else M.i2b(c, P[0]) + M.i2b(c, P[1])
+        assert bytes(out[i]) == exp, (i, e.hex())

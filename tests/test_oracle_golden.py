@@ -165,3 +165,23 @@ def test_config1_fixture_matches_model(cn):
         want = M.affine_mul(c, h2i(k), (h2i(px), h2i(py)))
         assert bytes.fromhex(out) == M.affine_bytes(c, (want[0], want[1], 0))
         assert M.affine_bytes(c, M.to_affine(c, M.mul_ref(c, (h2i(px), h2i(py), 1), h2i(k)))) == bytes.fromhex(out)
+
+
+@pytest.mark.parametrize("cn", ["k256", "p256", "p384"])
+def test_sec1_encoding_vectors(cn, ref_vectors):
+    """Base-point encodings of the reference's affine tests, and the all-zero identity (identity_encoding)."""
+    c = M.CURVES[cn]
+    e = ref_vectors[cn]["encoding"]
+    G = (c.gx, c.gy)
+    unc = bytes.fromhex(e["uncompressed_basepoint"])
+    assert unc == b"\x04" + M.i2b(c, c.gx) + M.i2b(c, c.gy)
+    comp = bytes.fromhex(e["compressed_basepoint"])
+    assert M.group_to_bytes(c, G) == comp
+    assert M.group_from_bytes(c, comp) == (True, G)
+    assert M.group_to_bytes(c, None) == bytes(c.nbytes + 1)
+    assert M.group_from_bytes(c, bytes(c.nbytes + 1)) == (True, None)
+    if "compact_basepoint" in e:
+        ok, P = M.group_from_bytes(c, bytes.fromhex(e["compact_basepoint"]))
+        assert ok and b"\x04" + M.i2b(c, P[0]) + M.i2b(c, P[1]) == bytes.fromhex(e["uncompact_basepoint"])
+    assert M.group_from_bytes(c, b"\x04" + bytes(c.nbytes))[0] is False
+    assert M.group_from_bytes(c, b"\x00" + b"\x01" * c.nbytes)[0] is False
