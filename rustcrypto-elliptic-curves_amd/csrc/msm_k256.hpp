@@ -4,7 +4,7 @@
 // a Straus interleaving with two 8-point tables per term - O(n) table memory and 128 shared
 // doublings, unusable at 2^20..2^26 terms.  The result is the same group element; the schedule here is
 //   1. signed c-bit digits of every scalar (c = 16: 16 windows + a carry window, 2^15 buckets per window)
-//   2. counting sort of the (term, window) pairs by bucket: histogram, exclusive scan, scatter
+//   2. counting sort of the (term, window) pairs by bucket: LDS-privatised histogram, exclusive scan, scatter
 //   3. one lane per bucket sums its points with Jacobian mixed additions (exceptional cases handled)
 //   4. per window sum_j j*B_j by segmented running sums, then Horner over the windows
 // Every stage is a kernel over device memory; no host round trips until the final point.
@@ -17,6 +17,7 @@ namespace msm {
 constexpr int C = 16;                         // window bits
 constexpr int NWIN = 17;                      // 16 full windows + the carry of the signed recoding
 constexpr int NBUCKET = 1 << (C - 1);         // |digit| in 1..2^15
+constexpr int SORT_CHUNKS = 15;               // workgroups per window in the counting sort: 17 x 15 = 255, one per CU
 // bucket reduction tree: 2^15 buckets = NSEG1 x SEG1 x SEG0 per window
 constexpr int LOG_SEG0 = 5, SEG0 = 1 << LOG_SEG0;     // buckets per level-0 run
 constexpr int LOG_SEG1 = 5, SEG1 = 1 << LOG_SEG1;     // level-0 results per level-1 run

@@ -9,8 +9,8 @@ namespace msm {
 // Signed 16-bit digits of one term (registers only).  k > n/2 is replaced by n - k with the opposite sign
 // (then k < 2^255 and the carry window of the recoding is almost always empty; without this half of all
 // terms land in its single bucket and one lane sums them).  d[w] in [-2^15, 2^15), d[16] in {0, 1};
-// returns the sign flip.  A term whose point is the identity gets all-zero digits.
-__device__ __forceinline__ bool term_digits(int* d, const u32* scalars, const u32* points_xy, size_t i) {
+// returns the sign flip.  Terms whose point is the identity are not filtered here: the bucket sums skip them.
+__device__ __forceinline__ bool term_digits(int* d, const u32* scalars, size_t i) {
   u32 k[8];
   words_load_be<8>(k, scalars + i * 8);
   k256::scalar_reduce_once(k);
@@ -23,69 +23,114 @@ __device__ __forceinline__ bool term_digits(int* d, const u32* scalars, const u3
 #pragma unroll
     for (int w = 0; w < 8; w++) k[w] = flip ? t[w] : k[w];
   }
-  u32 z = 0;
-#pragma unroll
-  for (int w = 0; w < 16; w++) z |= points_xy[i * 16 + w];
-  const bool skip = (z == 0);
   u32 carry = 0;
 #pragma unroll
   for (int w = 0; w < 16; w++) {
     const u32 v = ((k[w >> 1] >> (16 * (w & 1))) & 0xFFFFu) + carry;
     carry = (v >= 0x8000u) ? 1u : 0u;      // v in [2^15, 2^16] becomes v - 2^16 with a carry
-    d[w] = skip ? 0 : (int)v - (int)(carry << 16);
+    d[w] = (int)v - (int)(carry << 16);
   }
-  d[16] = skip ? 0 : (int)carry;
+  d[16] = (int)carry;
   return flip;
 }
-
-// 1. bucket histogram (one lane per term, 17 atomics)
-__global__ void __launch_bounds__(256) hist_kernel(const u32* scalars, const u32* points_xy, size_t n, u32* hist) {
-  ECGPU_GRID_STRIDE(i, n) {
-    int d[NWIN];
-    (void)term_digits(d, scalars, points_xy, i);
+// digit `w` (uniform over the workgroup) of term i and the sign of its bucket entry
+__device__ __forceinline__ int term_digit(const u32* scalars, size_t i, int w, bool& negative) {
+  int d[NWIN];
+  const bool flip = term_digits(d, scalars, i);
+  int v = d[0];
 #pragma unroll
-    for (int w = 0; w < NWIN; w++)
-      if (d[w] != 0) atomicAdd(&hist[w * NBUCKET + (d[w] < 0 ? -d[w] : d[w]) - 1], 1u);
-  }
+  for (int q = 1; q < NWIN; q++) v = (w == q) ? d[q] : v;
+  negative = (v < 0) != flip;
+  return v < 0 ? -v : v;
 }
 
-// 2. exclusive scan of the histogram (one workgroup; 17 * 2^15 counters)
-__global__ void __launch_bounds__(1024) scan_kernel(const u32* hist, u32* offsets, u32* cursor, int total) {
-  __shared__ u32 part[1024];
+// Counting sort of the (term, window) pairs by bucket, privatised in LDS.  A workgroup owns one window and one
+// contiguous chunk of the terms (grid = NWIN x SORT_CHUNKS, one workgroup per CU: the 2^15 counters of a window
+// are 128 KB of its LDS), so every count and every cursor increment is an LDS atomic; global memory sees only
+// the per-workgroup histograms (coalesced) and the scattered 4-byte index writes.  (The first version issued
+// 2 x 17 global atomics per term: 17.5 of the 32 ms of a 2^23-term MSM.)
+__device__ __forceinline__ void chunk_range(size_t n, int g, size_t& lo, size_t& hi) {
+  lo = n * (size_t)g / SORT_CHUNKS;
+  hi = n * (size_t)(g + 1) / SORT_CHUNKS;
+}
+// 1. part[w][g][b] = number of terms of chunk g whose window-w digit has magnitude b + 1
+__global__ void __launch_bounds__(1024) hist_kernel(const u32* scalars, size_t n, u32* part) {
+  __shared__ u32 cnt[NBUCKET];
+  const int w = blockIdx.x / SORT_CHUNKS, g = blockIdx.x % SORT_CHUNKS;
+  for (int b = threadIdx.x; b < NBUCKET; b += 1024) cnt[b] = 0;
+  __syncthreads();
+  size_t lo, hi;
+  chunk_range(n, g, lo, hi);
+  for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    bool neg;
+    const int a = term_digit(scalars, i, w, neg);
+    if (a) atomicAdd(&cnt[a - 1], 1u);
+  }
+  __syncthreads();
+  u32* dst = part + (size_t)blockIdx.x * NBUCKET;
+  for (int b = threadIdx.x; b < NBUCKET; b += 1024) dst[b] = cnt[b];
+}
+// 2a. bucket totals: hist[w * NBUCKET + b] = sum over the chunks
+__global__ void __launch_bounds__(256) totals_kernel(const u32* part, u32* hist) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= NWIN * NBUCKET) return;
+  const int w = j / NBUCKET, b = j % NBUCKET;
+  u32 s = 0;
+#pragma unroll 1
+  for (int g = 0; g < SORT_CHUNKS; g++) s += part[((size_t)(w * SORT_CHUNKS + g)) * NBUCKET + b];
+  hist[j] = s;
+}
+
+// 2b. exclusive scan of the bucket totals (one workgroup; 17 * 2^15 counters)
+__global__ void __launch_bounds__(1024) scan_kernel(const u32* hist, u32* offsets, int total) {
+  __shared__ u32 psum[1024];
   const int t = threadIdx.x;
   const int per = (total + 1023) / 1024;
   const int lo = t * per, hi = (lo + per < total) ? lo + per : total;
   u32 s = 0;
   for (int j = lo; j < hi; j++) s += hist[j];
-  part[t] = s;
+  psum[t] = s;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
-    u32 v = (t >= off) ? part[t - off] : 0;
+    u32 v = (t >= off) ? psum[t - off] : 0;
     __syncthreads();
-    part[t] += v;
+    psum[t] += v;
     __syncthreads();
   }
-  u32 run = (t == 0) ? 0 : part[t - 1];
-  for (int j = lo; j < hi; j++) { offsets[j] = run; cursor[j] = run; run += hist[j]; }
-  if (t == 1023) offsets[total] = part[1023];
+  u32 run = (t == 0) ? 0 : psum[t - 1];
+  for (int j = lo; j < hi; j++) { offsets[j] = run; run += hist[j]; }
+  if (t == 1023) offsets[total] = psum[1023];
 }
-
-// 3. scatter the (term, sign) pairs into their buckets (digits recomputed: cheaper than storing and
-//    re-reading 34 bytes per term)
-__global__ void __launch_bounds__(256) scatter_kernel(const u32* scalars, const u32* points_xy, size_t n, u32* cursor, u32* sorted) {
-  ECGPU_GRID_STRIDE(i, n) {
-    int d[NWIN];
-    const bool flip = term_digits(d, scalars, points_xy, i);
-    // all 17 returning atomics are issued before any result is used, so their latencies overlap
-    u32 pos[NWIN];
-#pragma unroll
-    for (int w = 0; w < NWIN; w++) {
-      const int a = d[w] < 0 ? -d[w] : d[w];
-      pos[w] = a ? atomicAdd(&cursor[w * NBUCKET + a - 1], 1u) : 0u;
+// 2c. part[w][g][b] becomes the first output slot of chunk g inside bucket (w, b)
+__global__ void __launch_bounds__(256) cursors_kernel(u32* part, const u32* offsets) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= NWIN * NBUCKET) return;
+  const int w = j / NBUCKET, b = j % NBUCKET;
+  u32 run = offsets[j];
+#pragma unroll 1
+  for (int g = 0; g < SORT_CHUNKS; g++) {
+    u32* p = part + ((size_t)(w * SORT_CHUNKS + g)) * NBUCKET + b;
+    const u32 c = *p;
+    *p = run;
+    run += c;
+  }
+}
+// 3. scatter the (term, sign) pairs into their buckets; same workgroup -> (window, chunk) map as the histogram
+__global__ void __launch_bounds__(1024) scatter_kernel(const u32* scalars, size_t n, const u32* part, u32* sorted) {
+  __shared__ u32 cur[NBUCKET];
+  const int w = blockIdx.x / SORT_CHUNKS, g = blockIdx.x % SORT_CHUNKS;
+  const u32* src = part + (size_t)blockIdx.x * NBUCKET;
+  for (int b = threadIdx.x; b < NBUCKET; b += 1024) cur[b] = src[b];
+  __syncthreads();
+  size_t lo, hi;
+  chunk_range(n, g, lo, hi);
+  for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    bool neg;
+    const int a = term_digit(scalars, i, w, neg);
+    if (a) {
+      const u32 pos = atomicAdd(&cur[a - 1], 1u);
+      sorted[pos] = (u32)i | (neg ? 0x80000000u : 0u);
     }
-#pragma unroll
-    for (int w = 0; w < NWIN; w++)
-      if (d[w] != 0) sorted[pos[w]] = (u32)i | (((d[w] < 0) != flip) ? 0x80000000u : 0u);
   }
 }
 
@@ -99,6 +144,10 @@ __global__ void __launch_bounds__(256, 4) bucket_sum_kernel(const u32* points_xy
     for (u32 j = lo; j < hi; j++) {
       const u32 e = sorted[j];
       const u32* src = points_xy + (size_t)(e & 0x7FFFFFFFu) * 16;
+      u32 z = 0;
+#pragma unroll
+      for (int q = 0; q < 16; q++) z |= src[q];
+      if (z == 0) continue;                      // the identity (affine zeros) contributes nothing
       FeK256 x, y;
       k256::from_be_words(x, src);
       k256::from_be_words(y, src + 8);
@@ -144,34 +193,52 @@ __global__ void __launch_bounds__(64) sum_kernel(const JacK256* in, JacK256* out
 
 // 6. per window: combine NSEG1 level-1 results
 //      S_w = sumW0 + SEG0 * ( sum_{s1} (Wt1 - T1)  +  SEG1 * sum_{s1} s1 * T1 )
-__global__ void __launch_bounds__(64) window_kernel(const JacK256* t1, const JacK256* w1, const JacK256* sumw0, JacK256* win) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= NWIN) return;
-  JacK256 run, acc, inner, neg;
-  k256::set_zero(run.x); k256::set_zero(run.y); k256::set_zero(run.z);
-  acc = run; inner = run;
-#pragma unroll 1
-  for (int s = NSEG1 - 1; s >= 0; s--) {
-    jac_add(inner, inner, w1[w * NSEG1 + s]);
-    neg = t1[w * NSEG1 + s];
-    k256::neg(neg.y, neg.y);
-    jac_add(inner, inner, neg);                    // Wt1 - T1
-    if (s >= 1) {
-      jac_add(run, run, t1[w * NSEG1 + s]);
-      jac_add(acc, acc, run);                      // sum s1 * T1
+//    One workgroup per window, lane s1 owns one level-1 segment (and one of the NSUMW partial sums of the level-0
+//    weighted parts); the three sums over the lanes are LDS tree reductions, so the dependent chain is
+//    log2(32) additions instead of 32 x 4.
+__device__ __forceinline__ void lds_tree_sum(JacK256* sh, JacK256& v, int lane, int count) {
+  sh[lane] = v;
+  __syncthreads();
+  for (int off = count >> 1; off >= 1; off >>= 1) {
+    if (lane < off) {
+      JacK256 a = sh[lane], b = sh[lane + off];
+      jac_add(a, a, b);
+      sh[lane] = a;
     }
+    __syncthreads();
   }
+  v = sh[0];
+  __syncthreads();
+}
+__global__ void __launch_bounds__(NSEG1) window_kernel(const JacK256* t1, const JacK256* w1, const JacK256* sumw0, JacK256* win) {
+  static_assert(NSEG1 == 32 && NSUMW == 32, "one lane per level-1 segment and per partial sum");
+  __shared__ JacK256 sh[NSEG1];
+  const int w = blockIdx.x, s = threadIdx.x;          // blockDim.x == NSEG1
+  JacK256 inner, acc, sw;
+  k256::set_zero(acc.x); k256::set_zero(acc.y); k256::set_zero(acc.z);
+  const JacK256 T = t1[w * NSEG1 + s];
+  JacK256 neg = T;
+  k256::neg(neg.y, neg.y);
+  jac_add(inner, w1[w * NSEG1 + s], neg);            // Wt1 - T1
+  // s * T by double-and-add over the 5 bits of s
 #pragma unroll 1
-  for (int j = 0; j < LOG_SEG1; j++) k256::jac_double(acc);
-  jac_add(acc, acc, inner);
+  for (int bit = LOG_SEG1 - 1; bit >= 0; bit--) {
+    k256::jac_double(acc);
+    if ((s >> bit) & 1) jac_add(acc, acc, T);
+  }
+  sw = sumw0[w * NSUMW + s];
+  lds_tree_sum(sh, inner, s, NSEG1);
+  lds_tree_sum(sh, acc, s, NSEG1);
+  lds_tree_sum(sh, sw, s, NSEG1);
+  if (s == 0) {
 #pragma unroll 1
-  for (int j = 0; j < LOG_SEG0; j++) k256::jac_double(acc);
-  JacK256 sw;
-  k256::set_zero(sw.x); k256::set_zero(sw.y); k256::set_zero(sw.z);
+    for (int j = 0; j < LOG_SEG1; j++) k256::jac_double(acc);
+    jac_add(acc, acc, inner);
 #pragma unroll 1
-  for (int g = 0; g < NSUMW; g++) jac_add(sw, sw, sumw0[w * NSUMW + g]);
-  jac_add(acc, acc, sw);
-  win[w] = acc;
+    for (int j = 0; j < LOG_SEG0; j++) k256::jac_double(acc);
+    jac_add(acc, acc, sw);
+    win[w] = acc;
+  }
 }
 
 // 7. Horner over the windows, conversion to affine, output

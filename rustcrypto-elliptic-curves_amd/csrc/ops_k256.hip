@@ -41,10 +41,11 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t sz_aff = (pt_fmt == FMT_PROJECTIVE) ? al(n * 64) : 0;
   const size_t sz_hist = al((nb + 1) * 4), sz_sorted = al((size_t)NWIN * n * 4 + 4);
+  const size_t sz_part = al((size_t)NWIN * SORT_CHUNKS * NBUCKET * 4);
   const size_t sz_buckets = al(nb * sizeof(JacK256));
   const size_t n0 = (size_t)NWIN * NSEG0, n1 = (size_t)NWIN * NSEG1, nsw = (size_t)NWIN * NSUMW;
   const size_t sz_l0 = al(n0 * sizeof(JacK256)), sz_l1 = al(n1 * sizeof(JacK256)), sz_sw = al(nsw * sizeof(JacK256)), sz_win = al(NWIN * sizeof(JacK256));
-  const size_t need = sz_aff + 3 * sz_hist + sz_sorted + sz_buckets + 2 * sz_l0 + 2 * sz_l1 + sz_sw + sz_win;
+  const size_t need = sz_aff + 2 * sz_hist + sz_part + sz_sorted + sz_buckets + 2 * sz_l0 + 2 * sz_l1 + sz_sw + sz_win;
   if (need > c->msm_ws_cap) {
     if (c->msm_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->msm_ws)); c->msm_ws = nullptr; c->msm_ws_cap = 0; }
     HIPCHK(c, hipMalloc(&c->msm_ws, need));
@@ -54,7 +55,7 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   u32* aff = (u32*)p; p += sz_aff;
   u32* hist = (u32*)p; p += sz_hist;
   u32* offsets = (u32*)p; p += sz_hist;
-  u32* cursor = (u32*)p; p += sz_hist;
+  u32* part = (u32*)p; p += sz_part;
   u32* sorted = (u32*)p; p += sz_sorted;
   JacK256* buckets = (JacK256*)p; p += sz_buckets;
   JacK256* t0 = (JacK256*)p; p += sz_l0;
@@ -68,15 +69,17 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
     hipLaunchKernelGGL(to_affine_kernel, dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, pts, aff, n);
     xy = aff;
   }
-  HIPCHK(c, hipMemsetAsync(hist, 0, (nb + 1) * 4, c->stream));
-  if (n) hipLaunchKernelGGL(hist_kernel, dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, sc, xy, n, hist);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, c->stream, hist, offsets, cursor, (int)nb);
-  if (n) hipLaunchKernelGGL(scatter_kernel, dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, sc, xy, n, cursor, sorted);
+  const unsigned sort_grid = NWIN * SORT_CHUNKS, nb_grid = (unsigned)((nb + 255) / 256);
+  hipLaunchKernelGGL(hist_kernel, dim3(sort_grid), dim3(1024), 0, c->stream, sc, n, part);
+  hipLaunchKernelGGL(totals_kernel, dim3(nb_grid), dim3(256), 0, c->stream, (const u32*)part, hist);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u32*)hist, offsets, (int)nb);
+  hipLaunchKernelGGL(cursors_kernel, dim3(nb_grid), dim3(256), 0, c->stream, part, (const u32*)offsets);
+  hipLaunchKernelGGL(scatter_kernel, dim3(sort_grid), dim3(1024), 0, c->stream, sc, n, (const u32*)part, sorted);
   hipLaunchKernelGGL(bucket_sum_kernel, dim3(ecgpu_grid_for(c, nb, 16)), dim3(256), 0, c->stream, xy, offsets, sorted, buckets, (int)nb);
   hipLaunchKernelGGL(segment_kernel, dim3((unsigned)((n0 + 63) / 64)), dim3(64), 0, c->stream, buckets, t0, w0, SEG0, (int)n0);
   hipLaunchKernelGGL(segment_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, c->stream, t0, t1, w1, SEG1, (int)n1);
   hipLaunchKernelGGL(sum_kernel, dim3((unsigned)((nsw + 63) / 64)), dim3(64), 0, c->stream, w0, sumw0, SUMW_LEN, (int)nsw);
-  hipLaunchKernelGGL(window_kernel, dim3(1), dim3(64), 0, c->stream, t1, w1, sumw0, win);
+  hipLaunchKernelGGL(window_kernel, dim3(NWIN), dim3(NSEG1), 0, c->stream, t1, w1, sumw0, win);
   hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, c->stream, win, out, out_fmt);
   HIPCHK(c, hipGetLastError());
   return 0;
