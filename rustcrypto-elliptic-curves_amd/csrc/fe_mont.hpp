@@ -27,6 +27,9 @@ struct P256Mod {
   static constexpr int NTERM = 3;
   static constexpr int TERM_OFF[3] = {3, 6, 7};
   static constexpr u32 TERM_MUL[3] = {1u, 1u, 0xFFFFFFFFu};
+  // no subtracted terms: the one negative word of p + 1 (-2^224) is cheaper as the multiplier 2^32 - 1 above
+  static constexpr int NNEG = 0;
+  static constexpr int NEG_OFF[1] = {0};
 };
 struct P384Mod {
   static constexpr int N = 12;
@@ -38,10 +41,16 @@ struct P384Mod {
                                  0x00000000u, 0x00000002u, 0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u};
   static constexpr u32 ONE[12] = {0x00000001u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0x00000001u, 0x00000000u,
                                   0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u};
-  // p = -1 + 2^32 + 2^96 (2^288 - 2^32 - 1): word 1 and the nine words 3..11
-  static constexpr int NTERM = 10;
-  static constexpr int TERM_OFF[10] = {1, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-  static constexpr u32 TERM_MUL[10] = {1u, 0xFFFFFFFFu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  // p + 1 = 2^384 - 2^128 - 2^96 + 2^32: quotient digit m_i is added at words i + 1 and i + 12 and subtracted at
+  // words i + 3 and i + 4.  As all-positive words this would be ten terms (word 1 and the nine words 3..11 with
+  // multipliers 2^32 - 1 / 2^32 - 2), each a multiply-accumulate; the signed form is two additions and two
+  // 96-bit subtractions per digit (10 instead of 20 VALU instructions), the column accumulator being read as a
+  // two's-complement number while columns are in flight.
+  static constexpr int NTERM = 2;
+  static constexpr int TERM_OFF[2] = {1, 12};
+  static constexpr u32 TERM_MUL[2] = {1u, 1u};
+  static constexpr int NNEG = 2;
+  static constexpr int NEG_OFF[2] = {3, 4};
 };
 
 template <class M>
@@ -85,6 +94,17 @@ ECGPU_HD void fips_column(Acc96& c, const u32* a, const u32* b, const u32* m) {
     }
     mac_cols<TOT>(c, pa, pb);
   }
+#pragma unroll
+  for (int t = 0; t < M::NNEG; t++) {
+    const int i = K - M::NEG_OFF[t];
+    if (i >= 0 && i < N) acc_sub32(c, m[i]);
+  }
+}
+// shift the accumulator down one word; with subtracted terms it is signed while columns are in flight
+template <class M>
+ECGPU_HD u32 fips_pop(Acc96& c) {
+  if constexpr (M::NNEG > 0) return acc_pop_signed(c);
+  else return acc_pop(c);
 }
 
 template <class M, int K>
@@ -92,7 +112,7 @@ ECGPU_HD void fips_low(Acc96& c, const u32* a, const u32* b, u32* m) {
   if constexpr (K < M::N) {
     fips_column<M, K>(c, a, b, m);
     // m_K = low word of the column; the "-1" of p cancels it exactly, so popping it is all that happens here
-    m[K] = acc_pop(c);
+    m[K] = fips_pop<M>(c);
     fips_low<M, K + 1>(c, a, b, m);
   }
 }
@@ -100,7 +120,7 @@ template <class M, int K>
 ECGPU_HD void fips_high(Acc96& c, const u32* a, const u32* b, const u32* m, u32* t) {
   if constexpr (K < 2 * M::N - 1) {
     fips_column<M, K>(c, a, b, m);
-    t[K - M::N] = acc_pop(c);
+    t[K - M::N] = fips_pop<M>(c);
     fips_high<M, K + 1>(c, a, b, m, t);
   }
 }
@@ -113,6 +133,7 @@ ECGPU_HD void mul(FeMont<M>& r, const FeMont<M>& a, const FeMont<M>& b) {
   Acc96 c{0, 0};
   fips_low<M, 0>(c, a.v, b.v, m);
   fips_high<M, N>(c, a.v, b.v, m, t);
+  fips_column<M, 2 * N - 1>(c, a.v, b.v, m);      // no products left; reduction terms that reach the top word (offset N)
   t[N - 1] = (u32)c.lo;
   t[N] = (u32)(c.lo >> 32);
   // t < 2p: subtract p once if needed (p256 field.rs:272-276 sub_inner)

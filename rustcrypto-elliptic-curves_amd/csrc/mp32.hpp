@@ -159,6 +159,15 @@ ECGPU_HD void acc_add32(Acc96& c, u32 w) {
 #endif
 }
 
+// c -= w, the accumulator read as a 96-bit two's-complement number
+ECGPU_HD void acc_sub32(Acc96& c, u32 w) {
+  u32 l0 = (u32)c.lo, l1 = (u32)(c.lo >> 32), bw = 0;
+  l0 = subb(l0, w, bw);
+  l1 = subb(l1, 0u, bw);
+  c.hi = subb(c.hi, 0u, bw);
+  c.lo = ((u64)l1 << 32) | l0;
+}
+
 #include "mp32_cols.inc"
 
 // c += sum_{m < M} pa[m] * pb[m], issued as one asm statement
@@ -201,6 +210,14 @@ ECGPU_HD u32 acc_pop(Acc96& c) {
   u32 r = (u32)c.lo;
   c.lo = (c.lo >> 32) | ((u64)c.hi << 32);
   c.hi = 0;
+  return r;
+}
+
+// the same for a signed accumulator (arithmetic shift)
+ECGPU_HD u32 acc_pop_signed(Acc96& c) {
+  u32 r = (u32)c.lo;
+  c.lo = (c.lo >> 32) | ((u64)c.hi << 32);
+  c.hi = (u32)((int32_t)c.hi >> 31);
   return r;
 }
 

@@ -30,6 +30,12 @@ def test_field_ops(cn, cid, ref_vectors):
     xs = [a for a in edge for _ in edge] + [rng.randrange(p) for _ in range(1500)]
     ys = [b for _ in edge for b in edge] + [rng.randrange(p) for _ in range(1500)]
     assert fe_run(cid, c, 0, xs, ys) == [x * y % p for x, y in zip(xs, ys)]
+    # the same edge values as INTERNAL (Montgomery-form) operands: x = e R^-1 is stored as e
+    rinv = pow(1 << (8 * c.nbytes), -1, p)
+    hi = [p - 1, p - 2, 2**(8 * c.nbytes - 32) - 1, (1 << (8 * c.nbytes - 1)) % p, p - 2**32, p - 2**96, p - 2**128]
+    xm = [(a * rinv) % p for a in edge + hi for _ in edge + hi]
+    ym = [(b * rinv) % p for _ in edge + hi for b in edge + hi]
+    assert fe_run(cid, c, 0, xm, ym) == [x * y % p for x, y in zip(xm, ym)]
     assert fe_run(cid, c, 2, xs, ys) == [(x + y) % p for x, y in zip(xs, ys)]
     assert fe_run(cid, c, 3, xs, ys) == [(x - y) % p for x, y in zip(xs, ys)]
     assert fe_run(cid, c, 1, xs) == [x * x % p for x in xs]
