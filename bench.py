@@ -61,7 +61,7 @@ WORKLOADS = {
                            desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
     "p384_varbase":   dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
                            # 96 windows x (4 doublings (3M+5S) + 15/16 general additions (11M+5S)) + table (4 dbl + 3 add) + normalise
-                           modmul=96 * (32 + 15) + 80 + 7 + 72, mac=144, bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,2>",
+                           modmul=96 * (32 + 15) + 80 + 7 + 72, mac=144, bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,4>",
                            desc="p384 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
     "k256_msm":       dict(curve="k256", cid=0, log2n=23, fixed=False, msm=True, metric="k256 MSM points/sec", unit="points/s",
                            # 16 signed 16-bit windows: one mixed addition (8M+3S) per term per window; bucket reduction amortised
@@ -74,7 +74,7 @@ WORKLOADS = {
                            modmul=1764 + 230 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul16_kernel + k256_mul_fast_kernel<16,4> + verify_check",
                            desc="k256 ECDSA verify_prehashed (low-s rule), 2^%d independent (prehash, signature, public key) triples per GPU"),
     "p256_ecdsa_verify": dict(curve="p256", cid=1, log2n=22, fixed=False, msm=False, ecdsa=True, metric="p256 ECDSA verifications/sec", unit="verifications/s",
-                           modmul=3160 + 230 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul16_kernel + vb::mul_kernel<CurveP256,8,3> + verify_check",
+                           modmul=3160 + 230 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul16_kernel + vb::mul_kernel<CurveP256,8,4> + verify_check",
                            desc="p256 ECDSA verify_prehashed, 2^%d independent (prehash, signature, public key) triples per GPU"),
 }
 # v_mad_u64_u32 issues at half the FP32-FMA rate on gfx950 (measured, tools/ubench/valu_rates.hip):
