@@ -27,6 +27,11 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ecgpu.h but not exported"
     assert set(names) == set(ecgpu.EXPORTED_SYMBOLS)
+    # and nothing else leaves the library (csrc/ecgpu.map): the boundary is the C ABI only
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", ecgpu.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == set(names)
 
 
 def test_python_binding_declares_all_prototypes():

@@ -31,6 +31,18 @@ if mode == "lincomb2":
         ms = ctx.timer_stop()
         print(f"{cn} lincomb2 {'ref' if flags else 'default'}: n=2^{lg} {ms:.2f} ms  {n/ms*1e3/1e6:.3f} M lincombs/s", flush=True)
     sys.exit(0)
+if mode == "host":
+    # the same call with HOST buffers: staging copies (pageable memory) + kernel + copy back, end to end
+    import time, numpy as np
+    hs, hp = d_s.cpu().numpy(), None
+    cv.synth_points_device(d_p, n, synth.SEED); ctx.synchronize()
+    hp = d_p.cpu().numpy()
+    for rep in range(3):
+        t0 = time.perf_counter()
+        out, inf = cv.mul(hs, hp)
+        dt = time.perf_counter() - t0
+        print(f"{cn} var HOST buffers: n=2^{lg} {dt*1e3:.1f} ms  {n/dt/1e6:.2f} M scalar-mul/s  ({n*(3*nb+2*nb+1)/dt/1e9:.2f} GB/s over PCIe)", flush=True)
+    sys.exit(0)
 if mode == "ecdsa":
     # sign n prehashes on the device, then time verification of the valid batch
     d_k = torch.empty((n, nb), dtype=torch.uint8, device="cuda"); d_z = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
