@@ -97,6 +97,12 @@ const char* ecgpu_last_error(const ecgpu_ctx* ctx);
 const char* ecgpu_version(void);
 /* NB for a curve (32 / 32 / 48), 0 for an unknown curve. */
 size_t ecgpu_field_bytes(int curve);
+/* Page-locked host memory for ECGPU_MEM_HOST batches.  Host-buffer calls work with any memory; from pageable memory
+ * the transfers run at ~10 GB/s, from these buffers at PCIe rate, and batches of 2^21 elements or more are streamed
+ * through the device in chunks with upload, kernels and download overlapped. */
+int ecgpu_host_alloc(ecgpu_ctx* ctx, size_t bytes, void** out);
+int ecgpu_host_free(ecgpu_ctx* ctx, void* p);
+
 /* HIP-event timer on the context's stream: bracket launches, read milliseconds. */
 int ecgpu_timer_start(ecgpu_ctx* ctx);
 int ecgpu_timer_stop(ecgpu_ctx* ctx, float* milliseconds);

@@ -2,6 +2,9 @@
 // per-curve kernel launchers (ops_*.hip).  Host side of the boundary; all arithmetic happens in
 // the gfx950 kernels.  There is deliberately no CPU code path in this library.
 #include <string.h>
+#include <condition_variable>
+#include <thread>
+#include <vector>
 
 #include "ecgpu_internal.hpp"
 
@@ -48,6 +51,93 @@ static int buf_finish(ecgpu_ctx* c, Buf& b) {
 }
 static int finish_host(ecgpu_ctx* c, int mem) {
   if (mem == ECGPU_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-buffer calls on large batches: chunks of PIPE_CHUNK units flow through two device slots so that the
+// upload of chunk i+1, the kernels of chunk i and the download of chunk i-1 overlap.  Pageable host memory makes
+// hipMemcpyAsync block its caller, hence the download runs on a helper thread (own stream, ordered after the
+// chunk's kernels by an event); the calling thread uploads and launches.  Element i of every argument must depend
+// only on element i of the inputs (true for every batch entry point that uses this).
+// ---------------------------------------------------------------------------------------------
+static constexpr size_t PIPE_CHUNK = (size_t)1 << 20;
+static constexpr int PIPE_MAXARGS = 6;
+struct PipeArg {
+  const void* in;      // host input  (or nullptr)
+  void* out;           // host output (or nullptr)
+  size_t unit;         // bytes per batch element
+};
+template <class Launch>
+static int host_pipeline(ecgpu_ctx* c, const PipeArg* args, int nargs, size_t n, Launch launch) {
+  if (nargs > PIPE_MAXARGS) return ecgpu_set_err(c, ECGPU_ERR_ARG, "host_pipeline: too many arguments");
+  if (!c->copy_stream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_kernel[0], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_kernel[1], hipEventDisableTiming));
+  }
+  for (int s = 0; s < 2; s++)
+    for (int a = 0; a < nargs; a++) {
+      if (!args[a].in && !args[a].out) continue;
+      int rc = stage_reserve(c, 6 + s * PIPE_MAXARGS + a, PIPE_CHUNK * args[a].unit);
+      if (rc) return rc;
+    }
+  const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t launched = 0, drained = 0;        // chunks whose kernels are enqueued / whose outputs are back on the host
+  hipError_t copy_err = hipSuccess;
+  bool abort_flag = false;
+  std::thread drain([&] {
+    (void)hipSetDevice(c->device);
+    for (size_t ci = 0; ci < nchunks; ci++) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return launched > ci || abort_flag; });
+        if (abort_flag) return;
+      }
+      const int slot = (int)(ci & 1);
+      const size_t lo = ci * PIPE_CHUNK, cnt = (n - lo < PIPE_CHUNK) ? n - lo : PIPE_CHUNK;
+      hipError_t e = hipStreamWaitEvent(c->copy_stream, c->ev_kernel[slot], 0);
+      for (int a = 0; a < nargs && e == hipSuccess; a++)
+        if (args[a].out)
+          e = hipMemcpyAsync((char*)args[a].out + lo * args[a].unit, c->stage[6 + slot * PIPE_MAXARGS + a], cnt * args[a].unit,
+                             hipMemcpyDeviceToHost, c->copy_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+      std::lock_guard<std::mutex> lk(mu);
+      if (e != hipSuccess && copy_err == hipSuccess) copy_err = e;
+      drained = ci + 1;
+      cv.notify_all();
+    }
+  });
+  int rc = 0;
+  hipError_t up_err = hipSuccess;
+  for (size_t ci = 0; ci < nchunks && rc == 0 && up_err == hipSuccess; ci++) {
+    const int slot = (int)(ci & 1);
+    if (ci >= 2) {                         // the slot is free once chunk ci-2 has been downloaded
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return drained + 2 > ci; });
+    }
+    const size_t lo = ci * PIPE_CHUNK, cnt = (n - lo < PIPE_CHUNK) ? n - lo : PIPE_CHUNK;
+    void* dev[PIPE_MAXARGS];
+    for (int a = 0; a < nargs; a++) {
+      dev[a] = (args[a].in || args[a].out) ? c->stage[6 + slot * PIPE_MAXARGS + a] : nullptr;
+      if (args[a].in && up_err == hipSuccess)
+        up_err = hipMemcpyAsync(dev[a], (const char*)args[a].in + lo * args[a].unit, cnt * args[a].unit, hipMemcpyHostToDevice, c->stream);
+    }
+    if (up_err == hipSuccess) rc = launch(dev, cnt);
+    if (rc == 0 && up_err == hipSuccess) up_err = hipEventRecord(c->ev_kernel[slot], c->stream);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (rc != 0 || up_err != hipSuccess) abort_flag = true; else launched = ci + 1;
+      cv.notify_all();
+    }
+  }
+  drain.join();
+  (void)hipStreamSynchronize(c->stream);
+  if (rc) return rc;
+  if (up_err != hipSuccess) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "host pipeline upload: %s", hipGetErrorString(up_err));
+  if (copy_err != hipSuccess) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "host pipeline download: %s", hipGetErrorString(copy_err));
   return 0;
 }
 
@@ -106,7 +196,9 @@ void ecgpu_destroy(ecgpu_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (int i = 0; i < 6; i++) if (c->stage[i]) (void)hipFree(c->stage[i]);
+  for (int i = 0; i < ecgpu_ctx::NSTAGE; i++) if (c->stage[i]) (void)hipFree(c->stage[i]);
+  for (int i = 0; i < 2; i++) if (c->ev_kernel[i]) (void)hipEventDestroy(c->ev_kernel[i]);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   for (int i = 0; i < 3; i++) if (c->gen_table[i]) (void)hipFree(c->gen_table[i]);
   for (int i = 0; i < 3; i++) if (c->fb_table[i]) (void)hipFree(c->fb_table[i]);
   for (int i = 0; i < 3; i++) if (c->fb16_table[i]) (void)hipFree(c->fb16_table[i]);
@@ -130,6 +222,23 @@ int ecgpu_synchronize(ecgpu_ctx* c) {
   return ECGPU_OK;
 }
 const char* ecgpu_last_error(const ecgpu_ctx* c) { return c ? c->err : "null context"; }
+
+int ecgpu_host_alloc(ecgpu_ctx* c, size_t bytes, void** out) {
+  if (!c || !out) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return ECGPU_OK;
+}
+int ecgpu_host_free(ecgpu_ctx* c, void* p) {
+  if (!c) return ECGPU_ERR_ARG;
+  if (!p) return ECGPU_OK;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipHostFree(p));
+  return ECGPU_OK;
+}
 
 int ecgpu_timer_start(ecgpu_ctx* c) {
   if (!c) return ECGPU_ERR_ARG;
@@ -208,6 +317,13 @@ int ecgpu_lincomb_batch(ecgpu_ctx* c, int curve, const uint8_t* scalars, const u
   if (n == 0) return ECGPU_OK;
   ENTER(c, curve);
   const size_t pin = (pt_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb, pout = (out_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb;
+  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
+    const PipeArg args[4] = {{scalars, nullptr, terms * nb}, {points, nullptr, points ? terms * pin : 0}, {nullptr, out, pout},
+                             {nullptr, out_fmt == ECGPU_PT_AFFINE ? out_inf : nullptr, 1}};
+    return host_pipeline(c, args, 4, n, [&](void** d, size_t cnt) {
+      return ops->lincomb(c, (const uint32_t*)d[0], (const uint32_t*)d[1], pt_fmt, terms, (uint32_t*)d[2], out_fmt, (uint8_t*)d[3], cnt, flags);
+    });
+  }
   Buf bs, bp, bo, bi;
   int rc;
   if ((rc = buf_in(c, bs, 0, scalars, n * terms * nb, mem))) return rc;
@@ -319,6 +435,12 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* c, int curve, const uint8_t* prehash, co
   if (!c || !prehash || !sig_rs || !pubkeys_xy || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
   if (n == 0) return ECGPU_OK;
   ENTER(c, curve);
+  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
+    const PipeArg args[4] = {{prehash, nullptr, nb}, {sig_rs, nullptr, 2 * nb}, {pubkeys_xy, nullptr, 2 * nb}, {nullptr, ok, 1}};
+    return host_pipeline(c, args, 4, n, [&](void** d, size_t cnt) {
+      return ops->ecdsa_verify(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (const uint32_t*)d[2], (uint8_t*)d[3], cnt, flags);
+    });
+  }
   Buf bz, bs, bq, bo;
   int rc;
   if ((rc = buf_in(c, bz, 0, prehash, n * nb, mem))) return rc;
@@ -334,6 +456,14 @@ int ecgpu_ecdsa_sign_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, con
   if (!c || !secret_d || !nonce_k || !prehash || !sig_rs || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
   if (n == 0) return ECGPU_OK;
   ENTER(c, curve);
+  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
+    const PipeArg args[6] = {{secret_d, nullptr, nb}, {nonce_k, nullptr, nb}, {prehash, nullptr, nb}, {nullptr, sig_rs, 2 * nb},
+                             {nullptr, recovery_id, 1}, {nullptr, ok, 1}};
+    return host_pipeline(c, args, 6, n, [&](void** d, size_t cnt) {
+      return ops->ecdsa_sign(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (const uint32_t*)d[2], (uint32_t*)d[3], (uint8_t*)d[4], (uint8_t*)d[5], cnt,
+                             flags);
+    });
+  }
   Buf bd, bk, bz, bs, br, bo;
   int rc;
   if ((rc = buf_in(c, bd, 0, secret_d, n * nb, mem))) return rc;

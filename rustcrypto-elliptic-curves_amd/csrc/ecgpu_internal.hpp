@@ -19,8 +19,12 @@ struct ecgpu_ctx {
   char err[512] = {0};
   std::mutex mu;
   // grow-only device staging buffers for ECGPU_MEM_HOST calls
-  void* stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t stage_cap[6] = {0, 0, 0, 0, 0, 0};
+  static constexpr int NSTAGE = 18;          // 6 for whole-batch staging + 2 pipeline slots x 6 arguments
+  void* stage[NSTAGE] = {};
+  size_t stage_cap[NSTAGE] = {};
+  // second stream + events of the chunked host-buffer pipeline (ecgpu.hip: host_pipeline)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_kernel[2] = {nullptr, nullptr};
   // precomputed generator tables, one per curve, built on first use
   void* gen_table[3] = {nullptr, nullptr, nullptr};
   // fixed-base tables of the throughput schedule (fixedbase.hpp)

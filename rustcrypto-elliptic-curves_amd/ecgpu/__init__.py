@@ -63,6 +63,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.ecgpu_version.restype = ctypes.c_char_p
     lib.ecgpu_field_bytes.argtypes = [i]
     lib.ecgpu_field_bytes.restype = sz
+    lib.ecgpu_host_alloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    lib.ecgpu_host_free.argtypes = [vp, vp]
     lib.ecgpu_timer_start.argtypes = [vp]
     lib.ecgpu_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.ecgpu_field_op_batch.argtypes = [vp, i, i, u8p, u8p, u8p, sz, i]
@@ -99,7 +101,7 @@ EXPORTED_SYMBOLS = (
     "ecgpu_point_add_mixed_batch", "ecgpu_point_double_batch", "ecgpu_batch_normalize", "ecgpu_mul_batch",
     "ecgpu_lincomb_batch", "ecgpu_msm", "ecgpu_validate_scalars", "ecgpu_validate_points", "ecgpu_decompress_batch",
     "ecgpu_synth_scalars", "ecgpu_synth_points", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_sign_batch",
-    "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch",
+    "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free",
 )
 
 
@@ -127,9 +129,13 @@ class Context:
         if rc != 0:
             raise EcgpuError(f"ecgpu_create(device={device}) failed with {rc} (no usable gfx950 GPU? there is no CPU fallback)")
         self.device = device
+        self._pinned = []
 
     def close(self):
         if self.handle:
+            for p in self._pinned:
+                self.lib.ecgpu_host_free(self.handle, p)
+            self._pinned = []
             self.lib.ecgpu_destroy(self.handle)
             self.handle = ctypes.c_void_p()
 
@@ -148,6 +154,15 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.ecgpu_synchronize(self.handle))
+
+    def pinned_array(self, shape, dtype=np.uint8) -> np.ndarray:
+        """numpy array over page-locked host memory (ecgpu_host_alloc); freed with the context."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        self.check(self.lib.ecgpu_host_alloc(self.handle, nbytes, ctypes.byref(p)))
+        self._pinned.append(p)
+        buf = (ctypes.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def timer_start(self):
         self.check(self.lib.ecgpu_timer_start(self.handle))
@@ -222,19 +237,24 @@ class Curve:
         return out, inf
 
     # --- Mul<Scalar>, MulByGenerator, LinearCombination -----------------------------------------
-    def lincomb(self, scalars, points, terms: int = 1, point_format: int = AFFINE, out_format: int = AFFINE, flags: int = 0):
+    def lincomb(self, scalars, points, terms: int = 1, point_format: int = AFFINE, out_format: int = AFFINE, flags: int = 0,
+                out=None, out_inf=None):
+        """out / out_inf: optional preallocated result arrays (e.g. Context.pinned_array) instead of fresh ones."""
         s = _as_host(scalars, self.nb)
         n = len(s) // terms
         pw = (3 if point_format == PROJECTIVE else 2) * self.nb
         ow = (3 if out_format == PROJECTIVE else 2) * self.nb
         p = _as_host(points, pw) if points is not None else None
-        out, inf = _host_out(n, ow), np.zeros(n, dtype=np.uint8)
+        out = _host_out(n, ow) if out is None else out
+        inf = np.zeros(n, dtype=np.uint8) if out_inf is None else out_inf
+        if out.shape != (n, ow) or out.dtype != np.uint8 or inf.shape != (n,) or not out.flags.c_contiguous:
+            raise ValueError("out / out_inf have the wrong shape")
         self.ctx.check(self.ctx.lib.ecgpu_lincomb_batch(self.ctx.handle, self.id, _ptr(s)[0], _ptr(p)[0], point_format, terms,
                                                         _ptr(out)[0], out_format, _ptr(inf)[0], n, HOST, flags))
         return (out, inf) if out_format == AFFINE else out
 
-    def mul(self, scalars, points, point_format: int = AFFINE, out_format: int = AFFINE, flags: int = 0):
-        return self.lincomb(scalars, points, 1, point_format, out_format, flags)
+    def mul(self, scalars, points, point_format: int = AFFINE, out_format: int = AFFINE, flags: int = 0, out=None, out_inf=None):
+        return self.lincomb(scalars, points, 1, point_format, out_format, flags, out, out_inf)
 
     def mul_by_generator(self, scalars, out_format: int = AFFINE, flags: int = 0):
         return self.lincomb(scalars, None, 1, AFFINE, out_format, flags)
