@@ -191,6 +191,14 @@ int ecgpu_ecdsa_sign_batch(ecgpu_ctx* ctx, int curve, const uint8_t* secret_d, c
                            const uint8_t* prehash, uint8_t* sig_rs, uint8_t* recovery_id, uint8_t* ok,
                            size_t n, int mem, unsigned flags);
 
+/* ---- BIP340 Schnorr over secp256k1 -----------------------------------------------------------------
+ * The elliptic-curve part of VerifyingKey::verify_prehash (k256/src/schnorr/verifying.rs:62-93): with the challenge
+ * e = tagged_hash("BIP0340/challenge", r || P.x || m) supplied by the caller (32 bytes, reduced mod n here),
+ * ok[i] = 1 iff R = s G - e P is finite, has even y and x(R) = r.  Decoding rules of the reference apply: r in
+ * [1, p), s in [1, n) (k256/src/schnorr.rs:142-160), key x < p with a curve point (verifying.rs:39-45). */
+int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* pubkeys_x, const uint8_t* sig_rs,
+                               const uint8_t* challenges, uint8_t* ok, size_t n, int mem);
+
 /* ---- synthetic inputs for benchmarks (device memory only) ------------------------------------
  * Fill device buffers with the counter-based streams specified in oracle/synth.py:
  * scalars[i] = reduce(stream 0), points[i] = try-and-increment decompress of streams 1.. .

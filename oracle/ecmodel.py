@@ -671,3 +671,42 @@ def group_from_bytes(c: Curve, b: bytes):
     if not any(b):
         return True, None
     return False, None
+
+
+# --- BIP340 Schnorr (k256/src/schnorr.rs, schnorr/{signing,verifying}.rs) -------------------------------------------
+
+def _tagged_hash(tag: bytes, *parts: bytes) -> bytes:
+    import hashlib
+    t = hashlib.sha256(tag).digest()          # schnorr.rs:180-186
+    h = hashlib.sha256(t + t)
+    for p in parts:
+        h.update(p)
+    return h.digest()
+
+
+def schnorr_verify_prehash(px: bytes, msg: bytes, sig: bytes) -> bool:
+    """verifying.rs:39-45 (key decoding), schnorr.rs:142-160 (signature decoding), verifying.rs:62-93."""
+    c = K256
+    x, r, s = int.from_bytes(px, "big"), int.from_bytes(sig[:32], "big"), int.from_bytes(sig[32:], "big")
+    P = decompress(c, x, 0)
+    if P is None or not (0 < r < c.p) or not (0 < s < c.n) or len(msg) != 32:
+        return False
+    e = int.from_bytes(_tagged_hash(b"BIP0340/challenge", sig[:32], px, msg), "big") % c.n
+    R = affine_add(c, affine_mul(c, s, (c.gx, c.gy)), affine_mul(c, (c.n - e) % c.n, P))
+    return R is not None and R[1] % 2 == 0 and R[0] == r
+
+
+def schnorr_sign_prehash(d_bytes: bytes, msg: bytes, aux: bytes):
+    """signing.rs:80-131 -> (signature, x-only public key)."""
+    c = K256
+    d0 = int.from_bytes(d_bytes, "big")
+    P = affine_mul(c, d0, (c.gx, c.gy))
+    d = c.n - d0 if P[1] & 1 else d0
+    px = P[0].to_bytes(32, "big")
+    t = (d ^ int.from_bytes(_tagged_hash(b"BIP0340/aux", aux), "big")).to_bytes(32, "big")
+    k0 = int.from_bytes(_tagged_hash(b"BIP0340/nonce", t, px, msg), "big") % c.n
+    R = affine_mul(c, k0, (c.gx, c.gy))
+    k = c.n - k0 if R[1] & 1 else k0
+    r = R[0].to_bytes(32, "big")
+    e = int.from_bytes(_tagged_hash(b"BIP0340/challenge", r, px, msg), "big") % c.n
+    return r + ((k + e * d) % c.n).to_bytes(32, "big"), px

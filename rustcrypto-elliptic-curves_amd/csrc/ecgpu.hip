@@ -451,6 +451,27 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* c, int curve, const uint8_t* prehash, co
   if ((rc = buf_finish(c, bo))) return rc;
   return finish_host(c, mem);
 }
+int ecgpu_schnorr_verify_batch(ecgpu_ctx* c, int curve, const uint8_t* pubkeys_x, const uint8_t* sig_rs, const uint8_t* challenges, uint8_t* ok,
+                               size_t n, int mem) {
+  if (!c || !pubkeys_x || !sig_rs || !challenges || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (n == 0) return ECGPU_OK;
+  ENTER(c, curve);
+  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
+    const PipeArg args[4] = {{pubkeys_x, nullptr, nb}, {sig_rs, nullptr, 2 * nb}, {challenges, nullptr, nb}, {nullptr, ok, 1}};
+    return host_pipeline(c, args, 4, n, [&](void** d, size_t cnt) {
+      return ops->schnorr_verify(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (const uint32_t*)d[2], (uint8_t*)d[3], cnt);
+    });
+  }
+  Buf bx, bs, be, bo;
+  int rc;
+  if ((rc = buf_in(c, bx, 0, pubkeys_x, n * nb, mem))) return rc;
+  if ((rc = buf_in(c, bs, 1, sig_rs, n * 2 * nb, mem))) return rc;
+  if ((rc = buf_in(c, be, 4, challenges, n * nb, mem))) return rc;
+  if ((rc = buf_out(c, bo, 2, ok, n, mem))) return rc;
+  if ((rc = ops->schnorr_verify(c, (const uint32_t*)bx.dev, (const uint32_t*)bs.dev, (const uint32_t*)be.dev, (uint8_t*)bo.dev, n))) return rc;
+  if ((rc = buf_finish(c, bo))) return rc;
+  return finish_host(c, mem);
+}
 int ecgpu_ecdsa_sign_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, const uint8_t* nonce_k, const uint8_t* prehash, uint8_t* sig_rs,
                            uint8_t* recovery_id, uint8_t* ok, size_t n, int mem, unsigned flags) {
   if (!c || !secret_d || !nonce_k || !prehash || !sig_rs || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");

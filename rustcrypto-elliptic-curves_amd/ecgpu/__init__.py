@@ -81,6 +81,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.ecgpu_to_bytes_batch.argtypes = [vp, i, u8p, i, u8p, sz, i]
     lib.ecgpu_from_bytes_batch.argtypes = [vp, i, u8p, u8p, u8p, sz, i]
     lib.ecgpu_ecdsa_verify_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
+    lib.ecgpu_schnorr_verify_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i]
     lib.ecgpu_ecdsa_sign_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
     lib.ecgpu_synth_scalars.argtypes = [vp, i, ctypes.c_uint64, ctypes.c_uint64, u8p, sz]
     lib.ecgpu_synth_points.argtypes = [vp, i, ctypes.c_uint64, ctypes.c_uint64, u8p, sz]
@@ -101,7 +102,7 @@ EXPORTED_SYMBOLS = (
     "ecgpu_point_add_mixed_batch", "ecgpu_point_double_batch", "ecgpu_batch_normalize", "ecgpu_mul_batch",
     "ecgpu_lincomb_batch", "ecgpu_msm", "ecgpu_validate_scalars", "ecgpu_validate_points", "ecgpu_decompress_batch",
     "ecgpu_synth_scalars", "ecgpu_synth_points", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_sign_batch",
-    "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free",
+    "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch",
 )
 
 
@@ -327,6 +328,19 @@ class Curve:
         fl = self.default_ecdsa_flags() if flags is None else flags
         self.ctx.check(self.ctx.lib.ecgpu_ecdsa_verify_batch(self.ctx.handle, self.id, _ptr(d_prehash)[0], _ptr(d_sig_rs)[0], _ptr(d_pubkeys_xy)[0],
                                                              _ptr(d_ok)[0], n, DEVICE, fl))
+
+    def schnorr_verify(self, pubkeys_x, sig_rs, challenges) -> np.ndarray:
+        """EC part of BIP340 verification; challenges = tagged challenge hashes (ecgpu.schnorr computes them)."""
+        x, sg, e = _as_host(pubkeys_x, self.nb), _as_host(sig_rs, 2 * self.nb), _as_host(challenges, self.nb)
+        if not (len(x) == len(sg) == len(e)):
+            raise ValueError("key, signature and challenge batches differ in length")
+        ok = np.zeros(len(x), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ecgpu_schnorr_verify_batch(self.ctx.handle, self.id, _ptr(x)[0], _ptr(sg)[0], _ptr(e)[0], _ptr(ok)[0], len(x), HOST))
+        return ok
+
+    def schnorr_verify_device(self, d_pubkeys_x, d_sig_rs, d_challenges, d_ok, n: int):
+        self.ctx.check(self.ctx.lib.ecgpu_schnorr_verify_batch(self.ctx.handle, self.id, _ptr(d_pubkeys_x)[0], _ptr(d_sig_rs)[0], _ptr(d_challenges)[0],
+                                                               _ptr(d_ok)[0], n, DEVICE))
 
     def ecdsa_sign(self, secret_d, nonce_k, prehash, flags: Optional[int] = None):
         """-> (sig_rs, recovery_id, ok)"""

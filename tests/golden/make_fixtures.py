@@ -115,6 +115,31 @@ def encoding_vectors(curve):
     return out
 
 
+def bip340_vectors():
+    """k256/src/schnorr.rs:217-270 (sign vectors 0-3) and :307-430 (verify vectors 4-14)."""
+    t = read("k256/src/schnorr.rs")
+    t = t[t.index("mod tests"):]
+
+    def hexes(blk, name):
+        m = re.search(name + r":\s*hex!\(\s*((?:\"[^\"]*\"\s*)+)\)", blk)
+        return re.sub(r"[^0-9A-Fa-f]", "", m.group(1)).lower()
+
+    sign, verify = [], []
+    a, b = t.index("const BIP340_SIGN_VECTORS"), t.index("const BIP340_VERIFY_VECTORS")
+    for blk in t[a:b].split("SignVector {")[1:]:
+        if "secret_key: hex!" not in blk:
+            continue
+        sign.append({k: hexes(blk, k) for k in ("secret_key", "public_key", "aux_rand", "message", "signature")})
+    for blk in t[b:].split("VerifyVector {")[1:]:
+        if "public_key: hex!" not in blk:
+            continue
+        v = {k: hexes(blk, k) for k in ("public_key", "message", "signature")}
+        v["valid"] = bool(re.search(r"valid:\s*true", blk))
+        v["index"] = int(re.search(r"index:\s*(\d+)", blk).group(1))
+        verify.append(v)
+    return {"sign": sign, "verify": verify}
+
+
 def h2c_vectors(curve):
     t = read(f"{curve}/src/arithmetic/hash2curve.rs")
     i = t.index("const TEST_VECTORS")
@@ -160,6 +185,7 @@ def main():
     fx = {}
     for c in ("k256", "p256", "p384"):
         fx[c] = {"group": group_vectors(c), "ecdsa": ecdsa_vectors(c), "hash2curve": h2c_vectors(c), "encoding": encoding_vectors(c)}
+    fx["k256"]["bip340"] = bip340_vectors()
     fx["k256"]["field_dbl"] = field_dbl("k256")
     fx["p256"]["field_dbl"] = field_dbl("p256")
     fx["k256"]["field_kat"] = risc0_field_kats()

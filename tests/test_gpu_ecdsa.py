@@ -168,3 +168,46 @@ def test_large_batch_all_valid_and_sparse_invalid(ctx):
     want[::1000] = 0
     assert (v == want).all()
     ctx.set_stream(0)
+
+
+def test_bip340_schnorr_vectors_and_random(ctx, ref_vectors):
+    """BIP340 sign vectors 0-3 and verify vectors 4-14 of k256/src/schnorr.rs, then random signatures made through the
+    device (mul_by_generator) and systematic corruptions, all against the model."""
+    from ecgpu import schnorr
+    cv = ctx.curve("k256")
+    v = ref_vectors["k256"]["bip340"]
+    sigs, pxs = schnorr.sign_batch(cv, [bytes.fromhex(s["secret_key"]) for s in v["sign"]], [bytes.fromhex(s["message"]) for s in v["sign"]],
+                                   [bytes.fromhex(s["aux_rand"]) for s in v["sign"]])
+    assert [s.hex() for s in sigs] == [s["signature"] for s in v["sign"]]
+    assert [p.hex() for p in pxs] == [s["public_key"] for s in v["sign"]]
+    keys = [bytes.fromhex(t["public_key"]) for t in v["verify"]] + pxs
+    msgs = [bytes.fromhex(t["message"]) for t in v["verify"]] + [bytes.fromhex(s["message"]) for s in v["sign"]]
+    sg = [bytes.fromhex(t["signature"]) for t in v["verify"]] + sigs
+    want = [t["valid"] for t in v["verify"]] + [True] * 4
+    assert list(map(bool, schnorr.verify_batch(cv, keys, msgs, sg))) == want
+    rng = random.Random(340)
+    n = 300
+    sk = [rng.randrange(1, M.K256.n).to_bytes(32, "big") for _ in range(n)]
+    ms = [rng.randbytes(32) for _ in range(n)]
+    aux = [rng.randbytes(32) for _ in range(n)]
+    sigs, pxs = schnorr.sign_batch(cv, sk, ms, aux)
+    for i in range(0, n, 37):
+        assert (sigs[i], pxs[i]) == M.schnorr_sign_prehash(sk[i], ms[i], aux[i])
+    for i in range(10, n):
+        m = i % 9
+        b = bytearray(sigs[i])
+        if m == 0: b[5] ^= 1                                     # r changed
+        elif m == 1: b[40] ^= 1                                  # s changed
+        elif m == 2: ms[i] = rng.randbytes(32)
+        elif m == 3: pxs[i] = pxs[i - 1]
+        elif m == 4: b[32:] = M.K256.n.to_bytes(32, "big")       # s = n
+        elif m == 5: b[:32] = M.K256.p.to_bytes(32, "big")       # r = p
+        elif m == 6: b[32:] = bytes(32)                          # s = 0
+        sigs[i] = bytes(b)
+    got = schnorr.verify_batch(cv, pxs, ms, sigs)
+    good = 0
+    for i in range(n):
+        w = M.schnorr_verify_prehash(pxs[i], ms[i], sigs[i])
+        assert bool(got[i]) == w, (i, i % 9)
+        good += w
+    assert 50 < good < n

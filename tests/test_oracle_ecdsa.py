@@ -95,3 +95,14 @@ def test_c_oracle_matches_model_and_vectors(cn, ref_vectors):
     got = CO.ecdsa_verify_batch(cid, np.frombuffer(b"".join(zs), dtype=np.uint8), np.frombuffer(b"".join(sgs), dtype=np.uint8),
                                 np.frombuffer(b"".join(qs), dtype=np.uint8), low_s=(cn == "k256"))
     assert list(got) == want
+
+
+def test_bip340_vectors_pin_the_schnorr_model(ref_vectors):
+    v = ref_vectors["k256"]["bip340"]
+    assert len(v["sign"]) == 4 and len(v["verify"]) >= 10
+    for s in v["sign"]:
+        sig, px = M.schnorr_sign_prehash(bytes.fromhex(s["secret_key"]), bytes.fromhex(s["message"]), bytes.fromhex(s["aux_rand"]))
+        assert px.hex() == s["public_key"] and sig.hex() == s["signature"]
+        assert M.schnorr_verify_prehash(px, bytes.fromhex(s["message"]), sig)
+    for t in v["verify"]:
+        assert M.schnorr_verify_prehash(bytes.fromhex(t["public_key"]), bytes.fromhex(t["message"]), bytes.fromhex(t["signature"])) == t["valid"], t["index"]
