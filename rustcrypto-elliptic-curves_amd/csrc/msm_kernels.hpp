@@ -134,27 +134,93 @@ __global__ void __launch_bounds__(1024) scatter_kernel(const u32* scalars, size_
   }
 }
 
-// 4. one lane per bucket: sum of its points (Jacobian accumulator, mixed additions, gathered points)
-__global__ void __launch_bounds__(256, 4) bucket_sum_kernel(const u32* points_xy, const u32* offsets, const u32* sorted, JacK256* buckets, int nb) {
+// 4. bucket sums.  One lane per bucket sums its points (Jacobian accumulator, mixed additions, gathered points).
+//    A bucket with more than `cap` entries would serialise the whole launch on one lane (equal scalars - a plain sum
+//    of points is an MSM with all scalars 1 - put every term of a window into one bucket), so such buckets are only
+//    registered here: they are cut into chunks of `cap` entries, each chunk is summed by a whole workgroup
+//    (heavy_chunk_kernel) and the chunk sums are folded per bucket (heavy_finish_kernel).  Uniform scalars have no
+//    heavy buckets and the two extra kernels find an empty list.
+struct HeavyBucket { u32 bucket, base, chunks; };
+struct HeavyChunk { u32 bucket, index; };
+
+__device__ __forceinline__ void bucket_accumulate(JacK256& acc, const u32* points_xy, u32 e) {
+  const u32* src = points_xy + (size_t)(e & 0x7FFFFFFFu) * 16;
+  u32 z = 0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) z |= src[q];
+  if (z == 0) return;                          // the identity (affine zeros) contributes nothing
+  FeK256 x, y;
+  k256::from_be_words(x, src);
+  k256::from_be_words(y, src + 8);
+  if (e >> 31) k256::neg(y, y);
+  k256::jac_add_mixed(acc, x, y, nullptr);
+}
+__global__ void __launch_bounds__(256, 4) bucket_sum_kernel(const u32* points_xy, const u32* offsets, const u32* sorted, JacK256* buckets, int nb,
+                                                            u32 cap, u32* heavy_ctr, HeavyBucket* heavy, HeavyChunk* chunks) {
   ECGPU_GRID_STRIDE(b, (size_t)nb) {
     JacK256 acc;
     k256::set_zero(acc.x); k256::set_zero(acc.y); k256::set_zero(acc.z);
     const u32 lo = offsets[b], hi = offsets[b + 1];
+    if (hi - lo > cap) {
+      const u32 k = (hi - lo + cap - 1) / cap;
+      const u32 idx = atomicAdd(&heavy_ctr[0], 1u);
+      const u32 base = atomicAdd(&heavy_ctr[1], k);
+      heavy[idx] = HeavyBucket{(u32)b, base, k};
 #pragma unroll 1
-    for (u32 j = lo; j < hi; j++) {
-      const u32 e = sorted[j];
-      const u32* src = points_xy + (size_t)(e & 0x7FFFFFFFu) * 16;
-      u32 z = 0;
-#pragma unroll
-      for (int q = 0; q < 16; q++) z |= src[q];
-      if (z == 0) continue;                      // the identity (affine zeros) contributes nothing
-      FeK256 x, y;
-      k256::from_be_words(x, src);
-      k256::from_be_words(y, src + 8);
-      if (e >> 31) k256::neg(y, y);
-      k256::jac_add_mixed(acc, x, y, nullptr);
+      for (u32 j = 0; j < k; j++) chunks[base + j] = HeavyChunk{(u32)b, j};
+      continue;                                 // buckets[b] is written by heavy_finish_kernel
     }
+#pragma unroll 1
+    for (u32 j = lo; j < hi; j++) bucket_accumulate(acc, points_xy, sorted[j]);
     buckets[b] = acc;
+  }
+}
+
+// sum over the lanes of a workgroup through LDS (count = blockDim.x, a power of two)
+__device__ __forceinline__ void lds_tree_sum(JacK256* sh, JacK256& v, int lane, int count) {
+  sh[lane] = v;
+  __syncthreads();
+  for (int off = count >> 1; off >= 1; off >>= 1) {
+    if (lane < off) {
+      JacK256 a = sh[lane], b = sh[lane + off];
+      jac_add(a, a, b);
+      sh[lane] = a;
+    }
+    __syncthreads();
+  }
+  v = sh[0];
+  __syncthreads();
+}
+// 4b. one workgroup per chunk of a heavy bucket: lanes stride over the chunk, LDS tree sum
+__global__ void __launch_bounds__(256) heavy_chunk_kernel(const u32* points_xy, const u32* offsets, const u32* sorted, u32 cap, const u32* heavy_ctr,
+                                                          const HeavyChunk* chunks, JacK256* partial) {
+  __shared__ JacK256 sh[256];
+  const u32 total = heavy_ctr[1];
+  for (u32 c = blockIdx.x; c < total; c += gridDim.x) {
+    const HeavyChunk ch = chunks[c];
+    const u32 lo = offsets[ch.bucket] + ch.index * cap;
+    const u32 end = offsets[ch.bucket + 1];
+    const u32 hi = (end - lo > cap) ? lo + cap : end;
+    JacK256 acc;
+    k256::set_zero(acc.x); k256::set_zero(acc.y); k256::set_zero(acc.z);
+#pragma unroll 1
+    for (u32 j = lo + threadIdx.x; j < hi; j += 256) bucket_accumulate(acc, points_xy, sorted[j]);
+    lds_tree_sum(sh, acc, threadIdx.x, 256);
+    if (threadIdx.x == 0) partial[c] = acc;
+  }
+}
+// 4c. one workgroup per heavy bucket: fold its chunk sums
+__global__ void __launch_bounds__(256) heavy_finish_kernel(const u32* heavy_ctr, const HeavyBucket* heavy, const JacK256* partial, JacK256* buckets) {
+  __shared__ JacK256 sh[256];
+  const u32 total = heavy_ctr[0];
+  for (u32 h = blockIdx.x; h < total; h += gridDim.x) {
+    const HeavyBucket hb = heavy[h];
+    JacK256 acc;
+    k256::set_zero(acc.x); k256::set_zero(acc.y); k256::set_zero(acc.z);
+#pragma unroll 1
+    for (u32 j = threadIdx.x; j < hb.chunks; j += 256) jac_add(acc, acc, partial[hb.base + j]);
+    lds_tree_sum(sh, acc, threadIdx.x, 256);
+    if (threadIdx.x == 0) buckets[hb.bucket] = acc;
   }
 }
 
@@ -196,20 +262,6 @@ __global__ void __launch_bounds__(64) sum_kernel(const JacK256* in, JacK256* out
 //    One workgroup per window, lane s1 owns one level-1 segment (and one of the NSUMW partial sums of the level-0
 //    weighted parts); the three sums over the lanes are LDS tree reductions, so the dependent chain is
 //    log2(32) additions instead of 32 x 4.
-__device__ __forceinline__ void lds_tree_sum(JacK256* sh, JacK256& v, int lane, int count) {
-  sh[lane] = v;
-  __syncthreads();
-  for (int off = count >> 1; off >= 1; off >>= 1) {
-    if (lane < off) {
-      JacK256 a = sh[lane], b = sh[lane + off];
-      jac_add(a, a, b);
-      sh[lane] = a;
-    }
-    __syncthreads();
-  }
-  v = sh[0];
-  __syncthreads();
-}
 __global__ void __launch_bounds__(NSEG1) window_kernel(const JacK256* t1, const JacK256* w1, const JacK256* sumw0, JacK256* win) {
   static_assert(NSEG1 == 32 && NSUMW == 32, "one lane per level-1 segment and per partial sum");
   __shared__ JacK256 sh[NSEG1];

@@ -45,7 +45,13 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   const size_t sz_buckets = al(nb * sizeof(JacK256));
   const size_t n0 = (size_t)NWIN * NSEG0, n1 = (size_t)NWIN * NSEG1, nsw = (size_t)NWIN * NSUMW;
   const size_t sz_l0 = al(n0 * sizeof(JacK256)), sz_l1 = al(n1 * sizeof(JacK256)), sz_sw = al(nsw * sizeof(JacK256)), sz_win = al(NWIN * sizeof(JacK256));
-  const size_t need = sz_aff + 2 * sz_hist + sz_part + sz_sorted + sz_buckets + 2 * sz_l0 + 2 * sz_l1 + sz_sw + sz_win;
+  // heavy buckets (more than `cap` entries): at most L / cap of them, at most 2 L / cap + 1 chunks (msm_kernels.hpp, step 4)
+  const size_t L = (size_t)NWIN * n;
+  const u32 cap = (u32)((8 * (n / NBUCKET) > 2048) ? 8 * (n / NBUCKET) : 2048);
+  const size_t hmax = L / cap + 1, cmax = 2 * (L / cap) + 2;
+  const size_t sz_hctr = al(8), sz_heavy = al(hmax * sizeof(HeavyBucket)), sz_chunks = al(cmax * sizeof(HeavyChunk)), sz_partial = al(cmax * sizeof(JacK256));
+  const size_t need = sz_aff + 2 * sz_hist + sz_part + sz_sorted + sz_buckets + 2 * sz_l0 + 2 * sz_l1 + sz_sw + sz_win + sz_hctr + sz_heavy + sz_chunks +
+                      sz_partial;
   if (need > c->msm_ws_cap) {
     if (c->msm_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->msm_ws)); c->msm_ws = nullptr; c->msm_ws_cap = 0; }
     HIPCHK(c, hipMalloc(&c->msm_ws, need));
@@ -63,7 +69,11 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   JacK256* t1 = (JacK256*)p; p += sz_l1;
   JacK256* w1 = (JacK256*)p; p += sz_l1;
   JacK256* sumw0 = (JacK256*)p; p += sz_sw;
-  JacK256* win = (JacK256*)p;
+  JacK256* win = (JacK256*)p; p += sz_win;
+  u32* heavy_ctr = (u32*)p; p += sz_hctr;
+  HeavyBucket* heavy = (HeavyBucket*)p; p += sz_heavy;
+  HeavyChunk* chunks = (HeavyChunk*)p; p += sz_chunks;
+  JacK256* partial = (JacK256*)p;
   const u32* xy = pts;
   if (pt_fmt == FMT_PROJECTIVE) {
     hipLaunchKernelGGL(to_affine_kernel, dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, pts, aff, n);
@@ -75,7 +85,13 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u32*)hist, offsets, (int)nb);
   hipLaunchKernelGGL(cursors_kernel, dim3(nb_grid), dim3(256), 0, c->stream, part, (const u32*)offsets);
   hipLaunchKernelGGL(scatter_kernel, dim3(sort_grid), dim3(1024), 0, c->stream, sc, n, (const u32*)part, sorted);
-  hipLaunchKernelGGL(bucket_sum_kernel, dim3(ecgpu_grid_for(c, nb, 16)), dim3(256), 0, c->stream, xy, offsets, sorted, buckets, (int)nb);
+  HIPCHK(c, hipMemsetAsync(heavy_ctr, 0, 8, c->stream));
+  hipLaunchKernelGGL(bucket_sum_kernel, dim3(ecgpu_grid_for(c, nb, 16)), dim3(256), 0, c->stream, xy, offsets, sorted, buckets, (int)nb, cap, heavy_ctr,
+                     heavy, chunks);
+  hipLaunchKernelGGL(heavy_chunk_kernel, dim3((unsigned)c->num_cus * 8), dim3(256), 0, c->stream, xy, (const u32*)offsets, (const u32*)sorted, cap,
+                     (const u32*)heavy_ctr, (const HeavyChunk*)chunks, partial);
+  hipLaunchKernelGGL(heavy_finish_kernel, dim3((unsigned)c->num_cus), dim3(256), 0, c->stream, (const u32*)heavy_ctr, (const HeavyBucket*)heavy,
+                     (const JacK256*)partial, buckets);
   hipLaunchKernelGGL(segment_kernel, dim3((unsigned)((n0 + 63) / 64)), dim3(64), 0, c->stream, buckets, t0, w0, SEG0, (int)n0);
   hipLaunchKernelGGL(segment_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, c->stream, t0, t1, w1, SEG1, (int)n1);
   hipLaunchKernelGGL(sum_kernel, dim3((unsigned)((nsw + 63) / 64)), dim3(64), 0, c->stream, w0, sumw0, SUMW_LEN, (int)nsw);

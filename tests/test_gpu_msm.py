@@ -105,3 +105,24 @@ def test_structured_large(curve):
         tot = (tot + int.from_bytes(kb[32 * i:32 * i + 32], "big") * vals[i]) % N
     want = M.affine_mul(C, tot, (C.gx, C.gy))
     assert bytes(d_out.cpu().numpy()) == M.i2b(C, want[0]) + M.i2b(C, want[1])
+
+
+def test_heavy_buckets_equal_scalars(curve):
+    """Equal scalars put every term of a window into one bucket: those buckets are cut into chunks summed by whole
+    workgroups (msm_kernels.hpp step 4).  n = 20000 > cap = 2048, against the oracle's term-by-term sum."""
+    cv = curve
+    n = 20000
+    pts = CO.synth_points(0, n, synth.SEED, 4242)
+    ones = np.zeros((n, 32), dtype=np.uint8)
+    ones[:, 31] = 1
+    want = CO.msm_naive(0, ones, pts)
+    got = cv.msm(ones, pts)
+    assert bytes(got) == bytes(want[:64])
+    # one repeated 256-bit scalar (every window heavy) mixed with random ones, and some identity points
+    sc = CO.synth_scalars(0, n, synth.SEED, 4242)
+    sc[: n // 2] = sc[0]
+    pts[7] = 0
+    pts[n // 2 + 3] = 0
+    want = CO.msm_naive(0, sc, pts)
+    got = cv.msm(sc, pts)
+    assert bytes(got) == bytes(want[:64])
