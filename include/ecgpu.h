@@ -139,6 +139,9 @@ int ecgpu_mul_batch(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uin
 
 /* n independent linear combinations of `terms` terms each:
  *   out[i] = sum_j scalars[i*terms + j] * points[i*terms + j]
+ * terms = 1, 2: throughput or exact-reference schedules as for ecgpu_mul_batch.  3 <= terms <= 1024: one reference
+ * multiplication per term folded with the complete addition - the group element is specified, a PROJECTIVE result
+ * is a valid representative but not the reference's (X, Y, Z), ECGPU_EXACT_REFERENCE is refused.
  * LinearCombination::lincomb (terms = 2) / LinearCombinationExt::lincomb_ext (k256 mul.rs:313-393;
  * primeorder default projective.rs:415-420). */
 int ecgpu_lincomb_batch(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points,

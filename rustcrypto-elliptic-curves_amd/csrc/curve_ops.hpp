@@ -124,8 +124,12 @@ struct CurveOps {
       hipLaunchKernelGGL((lincomb_ref_kernel<C, 1>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
     } else if (terms == 2) {
       hipLaunchKernelGGL((lincomb_ref_kernel<C, 2>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
+    } else if (terms <= 1024 && !(flags & ECGPU_EXACT_REFERENCE)) {
+      hipLaunchKernelGGL((lincomb_sum_kernel<C>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, (int)terms, out, out_fmt, out_inf, n);
     } else {
-      return ecgpu_set_err(c, ECGPU_ERR_UNSUPPORTED, "lincomb_batch supports 1 or 2 terms per combination (use ecgpu_msm for large sums)");
+      return ecgpu_set_err(c, ECGPU_ERR_UNSUPPORTED,
+                           "lincomb_batch: more than 2 terms per combination is computed term by term (no exact-XYZ contract, at most 1024 terms; "
+                           "use ecgpu_msm for one large sum)");
     }
     HIPCHK(c, hipGetLastError());
     return 0;

@@ -180,6 +180,30 @@ __global__ void __launch_bounds__(256) lincomb_ref_kernel(const u32* scalars, co
   }
 }
 
+// n independent linear combinations of `terms` (a run-time count) terms: sum_t k_t P_t as one reference scalar
+// multiplication per term folded with the complete addition.  This is the primeorder default
+// (LinearCombination: x*k + y*l, primeorder/src/projective.rs:415-420) extended to any length; for k256, whose
+// lincomb_ext interleaves the terms over shared doublings (mul.rs:342-393), it is the same group element.
+template <class C>
+__global__ void __launch_bounds__(256) lincomb_sum_kernel(const u32* scalars, const u32* points, int pt_fmt, int terms, u32* out, int out_fmt,
+                                                          uint8_t* out_inf, size_t n) {
+  typename C::Pt tab[C::REF_TABLE_PTS];
+  ECGPU_GRID_STRIDE(i, n) {
+    typename C::Pt acc, p, r;
+    C::pt_identity(acc);
+    const int pw = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * C::NW;
+#pragma unroll 1
+    for (int t = 0; t < terms; t++) {
+      u32 k[C::NW];
+      C::scalar_load(k, scalars + (i * terms + t) * C::NW);
+      load_point<C>(p, points + (i * terms + t) * pw, pt_fmt);
+      C::mul_ref(r, p, k, tab);
+      C::pt_add(acc, acc, r);
+    }
+    if (out_fmt == FMT_PROJECTIVE) store_projective<C>(out + i * 3 * C::NW, acc);
+    else store_affine_from_projective<C>(out + i * 2 * C::NW, out_inf ? out_inf + i : nullptr, acc);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // k256 variable-base scalar multiplication, throughput schedule (mulfast_k256.hpp).

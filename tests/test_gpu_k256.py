@@ -237,3 +237,39 @@ def test_synth_streams_match_spec_and_device_pointers(curve):
         w = M.affine_mul(C, k, pt)
         assert bytes(o[i]) == M.i2b(C, w[0]) + M.i2b(C, w[1])
     assert not d_i.cpu().numpy().any()
+
+
+@pytest.mark.parametrize("cn", ["k256", "p256", "p384"])
+def test_lincomb_many_terms(cn):
+    """lincomb_ext over arrays longer than two (k256 mul.rs:325-340): 3, 5 and 16 terms per combination against the
+    model, including zero scalars, identity points and cancelling terms."""
+    import random
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cn)
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    rng = random.Random(77)
+    for terms in (3, 5, 16):
+        n = 40
+        ks = [[rng.randrange(c.n) for _ in range(terms)] for _ in range(n)]
+        ps = [[M.affine_mul(c, rng.randrange(1, c.n), (c.gx, c.gy)) for _ in range(terms)] for _ in range(n)]
+        ks[0][1] = 0
+        ps[1][2] = None
+        ps[2][1], ks[2][1] = ps[2][0], (c.n - ks[2][0]) % c.n            # terms 0 and 1 cancel
+        if terms == 3:
+            ks[2][2] = 0                                                  # whole combination is the identity
+        sb = b"".join(M.i2b(c, k) for row in ks for k in row)
+        pb = b"".join(bytes(2 * nb) if P is None else M.i2b(c, P[0]) + M.i2b(c, P[1]) for row in ps for P in row)
+        out, inf = cv.lincomb(sb, pb, terms=terms)
+        for i in range(n):
+            acc = None
+            for k, P in zip(ks[i], ps[i]):
+                acc = M.affine_add(c, acc, M.affine_mul(c, k, P) if P is not None else None)
+            if acc is None:
+                assert inf[i] == 1 and not bytes(out[i]).strip(b"\0")
+            else:
+                assert inf[i] == 0 and bytes(out[i]) == M.i2b(c, acc[0]) + M.i2b(c, acc[1]), (terms, i)
+    with pytest.raises(ecgpu.EcgpuError):
+        cv.lincomb(sb, pb, terms=16, flags=ecgpu.EXACT_REFERENCE)
+    ctx.close()
