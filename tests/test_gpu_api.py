@@ -18,13 +18,13 @@ def test_status_codes_and_last_error():
     lib, h = ctx.lib, ctx.handle
     buf = (ctypes.c_uint8 * 256)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.ecgpu_mul_batch(h, 7, p, p, 0, p, 0, None, 1, ecgpu.HOST, 0) == -3         # ECGPU_ERR_UNSUPPORTED: curve
+    assert lib.ecgpu_mul_batch(h, 7, p, p, 0, p, 0, None, 1, ecgpu.HOST, 0) == -4         # ECGPU_ERR_UNSUPPORTED: curve
     assert b"curve" in lib.ecgpu_last_error(h)
     assert lib.ecgpu_mul_batch(h, 0, None, p, 0, p, 0, None, 1, ecgpu.HOST, 0) == -1      # ECGPU_ERR_ARG: null scalars
     assert lib.ecgpu_mul_batch(h, 0, p, p, 5, p, 0, None, 1, ecgpu.HOST, 0) == -1         # bad point format
     assert lib.ecgpu_lincomb_batch(h, 0, p, p, 0, 0, p, 0, None, 1, ecgpu.HOST, 0) == -1  # zero terms
-    assert lib.ecgpu_msm(h, 1, p, p, 0, 1, p, 0, ecgpu.HOST) == -3                        # MSM is k256 only
-    assert lib.ecgpu_schnorr_verify_batch(h, 1, p, p, p, p, 1, ecgpu.HOST) == -3          # BIP340 is k256 only
+    assert lib.ecgpu_msm(h, 1, p, p, 0, 1, p, 0, ecgpu.HOST) == -4                        # MSM is k256 only
+    assert lib.ecgpu_schnorr_verify_batch(h, 1, p, p, p, p, 1, ecgpu.HOST) == -4          # BIP340 is k256 only
     assert lib.ecgpu_mul_batch(h, 0, p, p, 0, p, 0, None, 0, ecgpu.HOST, 0) == 0          # empty batch: no-op
     assert lib.ecgpu_field_op_batch(h, 0, 99, p, p, p, 1, ecgpu.HOST) == -1               # unknown field op
     bad = ctypes.c_void_p()
