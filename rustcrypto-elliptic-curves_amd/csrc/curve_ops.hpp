@@ -63,19 +63,20 @@ struct CurveOps {
     c->fb_table[C::ID] = tab;
     return 0;
   }
-  // wide table T16[j][d-1] = d 2^(16 j) G, 2^15 entries per window, built by multiplying the scalars d 2^(16 j)
-  // with the 8-bit-window kernel; used for large batches, where the build cost (one pass over 0.56 M points)
-  // is amortised
-  static int ensure_fb16_table(ecgpu_ctx* c) {
-    if (c->fb16_table[C::ID]) return 0;
+  // wide tables TW[j][d-1] = d 2^(WB j) G, 2^(WB-1) entries per window, built by multiplying the scalars d 2^(WB j)
+  // with the 8-bit-window kernel; used for large batches, where the build cost (one pass over 0.56 M points for
+  // WB = 16, 6.8 M for WB = 20) is amortised
+  template <int WB>
+  static int ensure_fb_wide_table(ecgpu_ctx* c, void** slot) {
+    if (*slot) return 0;
     int rc = ensure_fb_table(c);
     if (rc) return rc;
-    const size_t total = (size_t)fb::nwin16<C>() * fb::W16_ENTRIES;
+    const size_t total = (size_t)fb::nwin_wide<C, WB>() * fb::wide_entries<WB>();
     void *ks = nullptr, *xy = nullptr, *tab = nullptr;
     HIPCHK(c, hipMalloc(&ks, total * C::NB));
     HIPCHK(c, hipMalloc(&xy, total * 2 * C::NB));
     HIPCHK(c, hipMalloc(&tab, total * sizeof(AffEntry<C>)));
-    hipLaunchKernelGGL((fb::table_scalars_kernel<C>), dim3(ecgpu_grid_for(c, total, 8)), dim3(256), 0, c->stream, (u32*)ks, total);
+    hipLaunchKernelGGL((fb::table_scalars_kernel<C, WB>), dim3(ecgpu_grid_for(c, total, 8)), dim3(256), 0, c->stream, (u32*)ks, total);
     hipLaunchKernelGGL((fb::mul_kernel<C, 16, 4>), dim3(ecgpu_grid_for(c, total, 4)), dim3(256), 0, c->stream, (const u32*)ks,
                        (const AffEntry<C>*)c->fb_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, total);
     hipLaunchKernelGGL((fb::table_from_bytes_kernel<C>), dim3(ecgpu_grid_for(c, total, 8)), dim3(256), 0, c->stream, (const u32*)xy,
@@ -84,14 +85,24 @@ struct CurveOps {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(ks));
     HIPCHK(c, hipFree(xy));
-    c->fb16_table[C::ID] = tab;
+    *slot = tab;
     return 0;
   }
   static int mul_gen_fast(ecgpu_ctx* c, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
     int rc;
-    if (n >= ((size_t)1 << 18)) {
-      if ((rc = ensure_fb16_table(c))) return rc;
-      hipLaunchKernelGGL((fb::mul16_kernel<C, 16, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
+    // ECGPU_FB_WINDOW = 8 / 16 / 20 forces one table (measurements); default by batch size
+    static const int forced = [] { const char* e = getenv("ECGPU_FB_WINDOW"); return e ? atoi(e) : 0; }();
+    const int wb = forced ? forced : (n >= ((size_t)1 << 21) ? 20 : n >= ((size_t)1 << 18) ? 16 : 8);
+    if (wb == 20) {
+      if ((rc = ensure_fb_wide_table<20>(c, &c->fb20_table[C::ID]))) return rc;
+      hipLaunchKernelGGL((fb::mul_wide_kernel<C, 20, 16, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
+                         (const AffEntry<C>*)c->fb20_table[C::ID], out, out_fmt, out_inf, n);
+      HIPCHK(c, hipGetLastError());
+      return 1;
+    }
+    if (wb == 16) {
+      if ((rc = ensure_fb_wide_table<16>(c, &c->fb16_table[C::ID]))) return rc;
+      hipLaunchKernelGGL((fb::mul_wide_kernel<C, 16, 16, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
                          (const AffEntry<C>*)c->fb16_table[C::ID], out, out_fmt, out_inf, n);
       HIPCHK(c, hipGetLastError());
       return 1;

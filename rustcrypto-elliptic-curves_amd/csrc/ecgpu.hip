@@ -202,6 +202,7 @@ void ecgpu_destroy(ecgpu_ctx* c) {
   for (int i = 0; i < 3; i++) if (c->gen_table[i]) (void)hipFree(c->gen_table[i]);
   for (int i = 0; i < 3; i++) if (c->fb_table[i]) (void)hipFree(c->fb_table[i]);
   for (int i = 0; i < 3; i++) if (c->fb16_table[i]) (void)hipFree(c->fb16_table[i]);
+  for (int i = 0; i < 3; i++) if (c->fb20_table[i]) (void)hipFree(c->fb20_table[i]);
   if (c->msm_ws) (void)hipFree(c->msm_ws);
   if (c->tab_ws) (void)hipFree(c->tab_ws);
   if (c->ecdsa_ws) (void)hipFree(c->ecdsa_ws);

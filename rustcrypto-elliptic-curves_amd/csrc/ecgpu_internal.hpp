@@ -30,6 +30,7 @@ struct ecgpu_ctx {
   // fixed-base tables of the throughput schedule (fixedbase.hpp)
   void* fb_table[3] = {nullptr, nullptr, nullptr};
   void* fb16_table[3] = {nullptr, nullptr, nullptr};   // 16-bit-window variant for large batches
+  void* fb20_table[3] = {nullptr, nullptr, nullptr};   // 20-bit-window variant for very large batches
   // per-lane table workspace of the k256 variable-base kernel (grow-only)
   void* tab_ws = nullptr;
   size_t tab_ws_cap = 0;

@@ -20,10 +20,14 @@ namespace fb {
 constexpr int W = 8;
 constexpr int ENTRIES = 1 << (W - 1);                                   // |digit| in 1..128
 template <class C> constexpr int nwin() { return C::NB + 1; }            // one byte per window + the carry window
-// wide variant: 16-bit windows, 2^15 entries per window (35 MB per 256-bit curve: served from the
-// Infinity Cache rather than L2), half as many additions
-constexpr int W16_ENTRIES = 1 << 15;
-template <class C> constexpr int nwin16() { return C::NB / 2 + 1; }
+// wide variants: WB-bit windows, 2^(WB-1) entries per window, 8 NB / WB additions.
+//   WB = 16: 17 x 2^15 entries (36 MB per 256-bit curve, served from the Infinity Cache)      - batches >= 2^18
+//   WB = 20: 13 x 2^19 entries (436 MB per 256-bit curve, 1 GB for p384, HBM-resident gathers) - batches >= 2^21
+// When WB divides the scalar width the signed recoding can carry out of the top window (one extra window that only
+// ever sees digit 1); otherwise the top window has spare bits and absorbs the carry.
+template <int WB> constexpr int wide_entries() { return 1 << (WB - 1); }
+template <class C, int WB> constexpr bool wide_carry_window() { return (8 * C::NB) % WB == 0; }
+template <class C, int WB> constexpr int nwin_wide() { return (8 * C::NB + WB - 1) / WB + (wide_carry_window<C, WB>() ? 1 : 0); }
 
 // stage A: one lane per window computes d * 2^(8j) G, d = 1..128, in Jacobian coordinates
 template <class C>
@@ -148,26 +152,31 @@ __global__ void __launch_bounds__(256) table_from_bytes_kernel(const u32* xy, Af
     C::fe_load(table[e].y, xy + e * 2 * C::NW + C::NW);
   }
 }
-// scalars d * 2^(16 j) for j < nwin16, d = 1..2^15 (canonical big-endian bytes), reduced mod n
-template <class C>
+// scalars d * 2^(WB j) for j < nwin_wide, d = 1..2^(WB-1) (canonical big-endian bytes), reduced mod n
+template <class C, int WB>
 __global__ void __launch_bounds__(256) table_scalars_kernel(u32* out, size_t total) {
   constexpr int NW = C::NW;
   ECGPU_GRID_STRIDE(e, total) {
-    const int j = (int)(e / W16_ENTRIES);
-    u32 d = (u32)(e % W16_ENTRIES) + 1;
-    // the carry window only ever sees digit 1 (k <= n/2 after the sign fold): its other entries are never read
-    const bool carry_window = (j == nwin16<C>() - 1);
+    const int j = (int)(e / wide_entries<WB>());
+    u32 d = (u32)(e % wide_entries<WB>()) + 1;
+    // a carry window only ever sees digit 1 (k <= n/2 after the sign fold): its other entries are never read
+    const bool carry_window = wide_carry_window<C, WB>() && (j == nwin_wide<C, WB>() - 1);
     if (carry_window && d > 1) d = 1;
+    // likewise a top window with spare bits never sees a digit above 2^(bits it covers) (+ carry)
+    constexpr int TOP_BITS = 8 * C::NB - WB * (nwin_wide<C, WB>() - 1);
+    if (!wide_carry_window<C, WB>() && j == nwin_wide<C, WB>() - 1 && d > (1u << TOP_BITS)) d = 1;
     u32 k[NW + 1];
 #pragma unroll
     for (int w = 0; w <= NW; w++) k[w] = 0;
-    // d << (16 j): d <= 2^15 spans at most two 32-bit words
+    // d << (WB j): d <= 2^(WB-1) < 2^32 spans at most two 32-bit words
+    const int wi = (WB * j) >> 5, sh = (WB * j) & 31;
+    const u64 wide = (u64)d << sh;
 #pragma unroll
     for (int w = 0; w <= NW; w++) {
-      if (w == (j >> 1)) k[w] |= (j & 1) ? (d << 16) : d;
-      if (w == (j >> 1) + 1 && (j & 1)) k[w] |= d >> 16;
+      if (w == wi) k[w] |= (u32)wide;
+      if (w == wi + 1) k[w] |= (u32)(wide >> 32);
     }
-    // j = nwin16 - 1 gives d * 2^(8 NB) which exceeds the word array: reduce 2^(32 NW) = R mod n by subtraction
+    // the top window can give a value of 32 NW + a few bits, which exceeds the word array: reduce 2^(32 NW) = R mod n by subtraction
     u32 ord[NW];
     C::order(ord);
     if (k[NW]) {
@@ -193,8 +202,8 @@ __global__ void __launch_bounds__(256) table_scalars_kernel(u32* out, size_t tot
   }
 }
 
-template <class C, int BATCH, int WAVES>
-__global__ void __launch_bounds__(256, WAVES) mul16_kernel(const u32* scalars, const AffEntry<C>* table, u32* out, int out_fmt,
+template <class C, int WB, int BATCH, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars, const AffEntry<C>* table, u32* out, int out_fmt,
                                                            uint8_t* out_inf, size_t n) {
   constexpr int NW = C::NW;
   Jac<C> res[BATCH];
@@ -219,15 +228,18 @@ __global__ void __launch_bounds__(256, WAVES) mul16_kernel(const u32* scalars, c
       jac::set_infinity<C>(acc);
       u32 carry = 0;
 #pragma unroll 1
-      for (int j = 0; j < nwin16<C>(); j++) {
-        u32 word = 0;
+      for (int j = 0; j < nwin_wide<C, WB>(); j++) {
+        // WB bits of k from bit WB j (words beyond the scalar read as zero)
+        const int wi = (WB * j) >> 5, sh = (WB * j) & 31;
+        u32 w0 = 0, w1 = 0;
 #pragma unroll
-        for (int q = 0; q < NW; q++) word = (j >> 1) == q ? k[q] : word;
-        u32 d = ((j < 2 * NW) ? ((word >> (16 * (j & 1))) & 0xFFFFu) : 0u) + carry;
-        carry = (d >= 0x8000u) ? 1u : 0u;
-        const int sd = (int)d - (int)(carry << 16);
+        for (int q = 0; q < NW; q++) { w0 = (wi == q) ? k[q] : w0; w1 = (wi + 1 == q) ? k[q] : w1; }
+        const u64 pair = ((u64)w1 << 32) | w0;
+        u32 d = ((u32)(pair >> sh) & ((1u << WB) - 1u)) + carry;
+        carry = (d >= (1u << (WB - 1))) ? 1u : 0u;      // d in [2^(WB-1), 2^WB] becomes d - 2^WB with a carry
+        const int sd = (int)d - (int)(carry << WB);
         if (sd != 0) {
-          const AffEntry<C>* e = table + (size_t)j * W16_ENTRIES + ((sd < 0 ? -sd : sd) - 1);
+          const AffEntry<C>* e = table + (size_t)j * wide_entries<WB>() + ((sd < 0 ? -sd : sd) - 1);
           typename C::Fe x = e->x, y = e->y;
           if ((sd < 0) != flip) C::fe_neg(y, y);
           jac::add_mixed<C>(acc, x, y);

@@ -202,18 +202,25 @@ def test_validate_and_decompress(ctx, cn):
             assert okd[i] == 1 and bytes(out[i]) == M.i2b(c, want[0]) + M.i2b(c, want[1])
 
 
+@pytest.mark.parametrize("lg", [18, 21])
 @pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1), ("p384", 2)])
-def test_fixed_base_wide_table_path(ctx, cn, cid):
-    """Batches of 2^18 and more take the 16-bit-window table (fixedbase.hpp): edge scalars up front, a seeded
-    batch behind them, sampled against the C oracle (reference mul_by_generator)."""
+def test_fixed_base_wide_table_path(ctx, cn, cid, lg):
+    """Batches of 2^18 and more take the 16-bit-window table, 2^21 and more the 20-bit-window table (fixedbase.hpp):
+    edge scalars up front (digit boundaries of both recodings), a seeded batch behind them, sampled against the C
+    oracle (reference mul_by_generator)."""
     import torch
     c = M.CURVES[cn]
     cv = ctx.curve(cn)
     nb = c.nbytes
-    n = 1 << 18
+    n = 1 << lg
+    bits = 8 * nb
     edge = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, (c.n + 1) // 2, 0x8000, 0x7FFF, 0xFFFF, 0x10000, 0x80008000, (1 << (8 * nb - 1)) % c.n,
             (0x7FFF << (8 * nb - 16)) | ((1 << (8 * nb - 16)) - 1), c.n - 0x8000, c.n - 0x7FFF, int("8000" * (nb // 2), 16) % c.n,
-            int("7FFF" * (nb // 2), 16), int("FFFF" * (nb // 2), 16) % c.n]
+            int("7FFF" * (nb // 2), 16), int("FFFF" * (nb // 2), 16) % c.n,
+            # 20-bit windows: digits 2^19 - 1, 2^19, 2^20 - 1 in every window, carries rippling through all windows
+            0x7FFFF, 0x80000, 0xFFFFF, 0x100000, sum(0x7FFFF << (20 * j) for j in range(bits // 20)) % c.n,
+            sum(0x80000 << (20 * j) for j in range(bits // 20)) % c.n, sum(0xFFFFF << (20 * j) for j in range(bits // 20)) % c.n,
+            ((c.n - 1) // 2) - 0x80000, (1 << (bits - 2)) - 1, (1 << (bits - 2))]
     d_s = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
     cv.synth_scalars_device(d_s, n, synth.SEED, 424242)
     ctx.synchronize()
