@@ -111,13 +111,13 @@ ECGPU_HD void mul(FeK256& r, const FeK256& a, const FeK256& b) {
 // products, and for the low half also h[k]*977 and h[k-1]*1, go into a single statement.
 template <int K>
 ECGPU_HD void mul_high_column(u32* h, Acc96& c, const u32* a, const u32* b) {
-  mac_product_column<8, K, 0>(c, a, b, nullptr, nullptr);
+  mac_product_column<8, K, 0, true>(c, a, b, nullptr, nullptr);     // c.hi == 0: fresh accumulator or just popped
   h[K - 8] = acc_pop(c);
 }
 template <int K>
 ECGPU_HD void mul_low_column(u32* t, Acc96& c, const u32* a, const u32* b, const u32* h) {
   const u32 xa[1] = {h[K]}, xb[1] = {C_LO};
-  mac_product_column<8, K, 1>(c, a, b, xa, xb);
+  mac_product_column<8, K, 1, true>(c, a, b, xa, xb);
   t[K] = acc_pop(c);
 }
 ECGPU_HD void mul(FeK256& r, const FeK256& a, const FeK256& b) {

@@ -92,7 +92,7 @@ ECGPU_HD void fips_column(Acc96& c, const u32* a, const u32* b, const u32* m) {
       const int i = K - M::TERM_OFF[t];
       if (i >= 0 && i < N) { pa[n] = m[i]; pb[n] = M::TERM_MUL[t]; n++; }
     }
-    mac_cols<TOT>(c, pa, pb);
+    mac_cols<TOT, (M::NNEG == 0)>(c, pa, pb);      // unsigned accumulators are always popped to c.hi == 0
   }
 #pragma unroll
   for (int t = 0; t < M::NNEG; t++) {

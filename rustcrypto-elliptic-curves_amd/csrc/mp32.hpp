@@ -170,29 +170,35 @@ ECGPU_HD void acc_sub32(Acc96& c, u32 w) {
 
 #include "mp32_cols.inc"
 
-// c += sum_{m < M} pa[m] * pb[m], issued as one asm statement
-template <int M>
+// c += sum_{m < M} pa[m] * pb[m], issued as one asm statement.  FRESH: the caller knows c.hi == 0 (the accumulator was
+// just popped or zeroed); the first carry then produces c.hi instead of adding to it, which saves zeroing a register
+// per column.
+#ifndef ECGPU_MAC_FRESH
+#define ECGPU_MAC_FRESH 1          // 0: always read c.hi (A/B switch for tools/nopbench)
+#endif
+template <int M, bool FRESH_ARG = false>
 ECGPU_HD void mac_cols(Acc96& c, const u32* pa, const u32* pb) {
   static_assert(M >= 1, "column length");
+  constexpr bool FRESH = FRESH_ARG && (ECGPU_MAC_FRESH != 0);
   if constexpr (M > 12) {            // an asm statement takes at most 30 operands: split long columns
-    mac_cols<12>(c, pa, pb);
-    mac_cols<M - 12>(c, pa + 12, pb + 12);
+    mac_cols<12, FRESH>(c, pa, pb);
+    mac_cols<M - 12, false>(c, pa + 12, pb + 12);
   }
-  if constexpr (M == 1) mac_col1(c, pa[0], pb[0]);
-  if constexpr (M == 2) mac_col2(c, pa[0], pb[0], pa[1], pb[1]);
-  if constexpr (M == 3) mac_col3(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2]);
-  if constexpr (M == 4) mac_col4(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3]);
-  if constexpr (M == 5) mac_col5(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4]);
-  if constexpr (M == 6) mac_col6(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5]);
-  if constexpr (M == 7) mac_col7(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6]);
-  if constexpr (M == 8) mac_col8(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7]);
-  if constexpr (M == 9) mac_col9(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8]);
-  if constexpr (M == 10) mac_col10(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9]);
-  if constexpr (M == 11) mac_col11(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9], pa[10], pb[10]);
-  if constexpr (M == 12) mac_col12(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9], pa[10], pb[10], pa[11], pb[11]);
+  if constexpr (M == 1) { if constexpr (FRESH) mac_col1_f(c, pa[0], pb[0]); else mac_col1(c, pa[0], pb[0]); }
+  if constexpr (M == 2) { if constexpr (FRESH) mac_col2_f(c, pa[0], pb[0], pa[1], pb[1]); else mac_col2(c, pa[0], pb[0], pa[1], pb[1]); }
+  if constexpr (M == 3) { if constexpr (FRESH) mac_col3_f(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2]); else mac_col3(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2]); }
+  if constexpr (M == 4) { if constexpr (FRESH) mac_col4_f(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3]); else mac_col4(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3]); }
+  if constexpr (M == 5) { if constexpr (FRESH) mac_col5_f(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4]); else mac_col5(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4]); }
+  if constexpr (M == 6) { if constexpr (FRESH) mac_col6_f(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5]); else mac_col6(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5]); }
+  if constexpr (M == 7) { if constexpr (FRESH) mac_col7_f(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6]); else mac_col7(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6]); }
+  if constexpr (M == 8) { if constexpr (FRESH) mac_col8_f(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7]); else mac_col8(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7]); }
+  if constexpr (M == 9) { if constexpr (FRESH) mac_col9_f(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8]); else mac_col9(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8]); }
+  if constexpr (M == 10) { if constexpr (FRESH) mac_col10_f(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9]); else mac_col10(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9]); }
+  if constexpr (M == 11) { if constexpr (FRESH) mac_col11_f(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9], pa[10], pb[10]); else mac_col11(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9], pa[10], pb[10]); }
+  if constexpr (M == 12) { if constexpr (FRESH) mac_col12_f(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9], pa[10], pb[10], pa[11], pb[11]); else mac_col12(c, pa[0], pb[0], pa[1], pb[1], pa[2], pb[2], pa[3], pb[3], pa[4], pb[4], pa[5], pb[5], pa[6], pb[6], pa[7], pb[7], pa[8], pb[8], pa[9], pb[9], pa[10], pb[10], pa[11], pb[11]); }
 }
 // column k of the N x N schoolbook product: sum_{i+j=k} a_i b_j, plus NX extra products (xa, xb)
-template <int N, int K, int NX>
+template <int N, int K, int NX, bool FRESH = false>
 ECGPU_HD void mac_product_column(Acc96& c, const u32* a, const u32* b, const u32* xa, const u32* xb) {
   constexpr int LO = (K - (N - 1)) > 0 ? (K - (N - 1)) : 0;
   constexpr int HI = K < (N - 1) ? K : (N - 1);
@@ -202,7 +208,7 @@ ECGPU_HD void mac_product_column(Acc96& c, const u32* a, const u32* b, const u32
   for (int m = 0; m < M; m++) { pa[m] = a[LO + m]; pb[m] = b[K - LO - m]; }
 #pragma unroll
   for (int m = 0; m < NX; m++) { pa[M + m] = xa[m]; pb[M + m] = xb[m]; }
-  mac_cols<M + NX>(c, pa, pb);
+  mac_cols<M + NX, FRESH>(c, pa, pb);
 }
 
 // pop the low word and shift the accumulator down by 32 bits
@@ -250,7 +256,7 @@ ECGPU_HD void mac_cross_column(Acc96& c, const u32* a) {
     u32 pa[M], pb[M];
 #pragma unroll
     for (int m = 0; m < M; m++) { pa[m] = a[LO + m]; pb[m] = a[K - LO - m]; }
-    mac_cols<M>(c, pa, pb);
+    mac_cols<M, true>(c, pa, pb);        // every cross column starts from a popped (or zero) accumulator
   }
 }
 template <int N, int K>
