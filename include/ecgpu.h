@@ -194,6 +194,15 @@ int ecgpu_ecdsa_sign_batch(ecgpu_ctx* ctx, int curve, const uint8_t* secret_d, c
                            const uint8_t* prehash, uint8_t* sig_rs, uint8_t* recovery_id, uint8_t* ok,
                            size_t n, int mem, unsigned flags);
 
+/* Public-key recovery, VerifyingKey::recover_from_prehash (external ecdsa crate; exercised by k256/src/ecdsa.rs:259-336):
+ * R = decompress(r, or r + n when recovery_id bit 1 is set; y parity = bit 0), Q = -(z r^-1) G + (s r^-1) R.
+ * pubkeys_xy[i] = Q and ok[i] = 1, or zeros and ok[i] = 0 where the reference returns Err: r or s outside [1, n-1],
+ * recovery id above 3, x not below p or without a square root, Q the identity, and - with ECGPU_ECDSA_LOW_S, as the
+ * reference's final verify_prehash does for secp256k1 - s in the high half. */
+int ecgpu_ecdsa_recover_batch(ecgpu_ctx* ctx, int curve, const uint8_t* prehash, const uint8_t* sig_rs,
+                              const uint8_t* recovery_id, uint8_t* pubkeys_xy, uint8_t* ok, size_t n, int mem,
+                              unsigned flags);
+
 /* ---- BIP340 Schnorr over secp256k1 -----------------------------------------------------------------
  * The elliptic-curve part of VerifyingKey::verify_prehash (k256/src/schnorr/verifying.rs:62-93): with the challenge
  * e = tagged_hash("BIP0340/challenge", r || P.x || m) supplied by the caller (32 bytes, reduced mod n here),

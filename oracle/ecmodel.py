@@ -710,3 +710,23 @@ def schnorr_sign_prehash(d_bytes: bytes, msg: bytes, aux: bytes):
     r = R[0].to_bytes(32, "big")
     e = int.from_bytes(_tagged_hash(b"BIP0340/challenge", r, px, msg), "big") % c.n
     return r + ((k + e * d) % c.n).to_bytes(32, "big"), px
+
+
+def ecdsa_recover_prehashed(c: Curve, z: bytes, r: int, s: int, recid: int, reject_high_s: bool = False):
+    """VerifyingKey::recover_from_prehash (external ecdsa crate, recovery.rs; exercised by k256/src/ecdsa.rs:259-336)
+    -> affine public key (x, y) or None."""
+    n = c.n
+    if not (0 < r < n and 0 < s < n) or recid > 3:
+        return None
+    if reject_high_s and s > n // 2:
+        return None                    # the closing verify_prehash rejects it on secp256k1
+    x = r + n if recid & 2 else r
+    if x >> (8 * c.nbytes):
+        return None
+    R = decompress(c, x, recid & 1)
+    if R is None:
+        return None
+    e = int.from_bytes(z, "big") % n
+    ri = pow(r, -1, n)
+    u1, u2 = (-(ri * e)) % n, ri * s % n
+    return affine_add(c, affine_mul(c, u1, (c.gx, c.gy)), affine_mul(c, u2, R))

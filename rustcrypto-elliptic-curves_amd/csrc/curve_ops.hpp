@@ -223,6 +223,28 @@ struct CurveOps {
     HIPCHK(c, hipGetLastError());
     return 0;
   }
+  static int ecdsa_recover(ecgpu_ctx* c, const u32* z, const u32* sig, const uint8_t* recid, u32* out_xy, uint8_t* ok, size_t n, unsigned flags) {
+    const size_t sz_s = al256(n * C::NB), sz_p = al256(n * 2 * C::NB), sz_f = al256(n);
+    int rc = ecdsa_reserve(c, 2 * sz_s + 3 * sz_p + 2 * sz_f);
+    if (rc) return rc;
+    char* p = (char*)c->ecdsa_ws;
+    u32* u1 = (u32*)p; p += sz_s;
+    u32* u2 = (u32*)p; p += sz_s;
+    u32* r_xy = (u32*)p; p += sz_p;
+    u32* a = (u32*)p; p += sz_p;
+    u32* b = (u32*)p; p += sz_p;
+    uint8_t* a_inf = (uint8_t*)p; p += sz_f;
+    uint8_t* b_inf = (uint8_t*)p;
+    hipLaunchKernelGGL((ecdsa::recover_prep_kernel<C, 16>), dim3(ecgpu_grid_for(c, (n + 15) / 16, 4)), dim3(256), 0, c->stream, z, sig, recid, r_xy, u1,
+                       u2, ok, n, flags);
+    HIPCHK(c, hipGetLastError());
+    if ((rc = lincomb(c, u1, nullptr, FMT_AFFINE, 1, a, FMT_AFFINE, a_inf, n, 0))) return rc;
+    if ((rc = lincomb(c, u2, r_xy, FMT_AFFINE, 1, b, FMT_AFFINE, b_inf, n, 0))) return rc;
+    hipLaunchKernelGGL((ecdsa::recover_finish_kernel<C, 16>), dim3(ecgpu_grid_for(c, (n + 15) / 16, 8)), dim3(256), 0, c->stream, (const u32*)a,
+                       (const uint8_t*)a_inf, (const u32*)b, (const uint8_t*)b_inf, out_xy, ok, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   // BIP340 verification (schnorr_kernels.hpp), secp256k1 only
   static int schnorr_verify(ecgpu_ctx* c, const u32* px, const u32* sig, const u32* e, uint8_t* ok, size_t n) {
     if constexpr (C::ID != 0) {
@@ -264,7 +286,7 @@ struct CurveOps {
   }
   static const ecgpu_curve_ops* table() {
     static const ecgpu_curve_ops t = {field_op, point_op, normalize, lincomb, msm, validate_scalars, validate_points,
-                                      decompress, synth_scalars, synth_points, to_bytes, from_bytes, ecdsa_verify, schnorr_verify, ecdsa_sign};
+                                      decompress, synth_scalars, synth_points, to_bytes, from_bytes, ecdsa_verify, ecdsa_recover, schnorr_verify, ecdsa_sign};
     return &t;
   }
 };

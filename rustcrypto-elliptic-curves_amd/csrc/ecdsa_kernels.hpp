@@ -268,5 +268,158 @@ __global__ void __launch_bounds__(256) sign_finish_kernel(const u32* d, const u3
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Public-key recovery (VerifyingKey::recover_from_prehash of the external ecdsa crate, exercised by
+// k256/src/ecdsa.rs:259-336): R = decompress(r [+ n], y_is_odd), Q = -(z r^-1) G + (s r^-1) R.
+//   recover_prep -> fixed-base kernel (u1 G) -> variable-base kernel (u2 R) -> recover_finish (affine sum)
+// ---------------------------------------------------------------------------------------------
+template <class C, int BATCH>
+__global__ void __launch_bounds__(256) recover_prep_kernel(const u32* z, const u32* sig, const uint8_t* recid, u32* r_xy, u32* u1, u32* u2,
+                                                           uint8_t* ok, size_t n, unsigned flags) {
+  using O = OrderOf<C>;
+  using Fe = typename C::Fe;
+  constexpr int L = O::L;
+  u32 w[BATCH][L];
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t base = tid; base < n; base += T * BATCH) {
+    int cnt = 0;
+    u32 good = 0;
+#pragma unroll 1
+    for (int b = 0; b < BATCH; b++) {
+      const size_t i = base + (size_t)b * T;
+      if (i >= n) break;
+      u32 r[L], s[L], x[L], ord[L], pm[L];
+      load_be<L>(r, sig + i * 2 * L);
+      load_be<L>(s, sig + i * 2 * L + L);
+      bool g = in_range<O>(r) && in_range<O>(s) && recid[i] < 4;
+      if ((flags & ECDSA_LOW_S) && is_high<O>(s)) g = false;     // the final verify_prehash of the reference rejects it
+      // x coordinate of R: r, or r + n when the recovery id says x was reduced; must stay below p
+      smont::order<O>(ord);
+      C::modulus(pm);
+      mp_copy<L>(x, r);
+      if (recid[i] & 2) {
+        const u32 cy = mp_add<L>(x, r, ord);
+        if (cy || mp_geq<L>(x, pm)) g = false;
+      }
+      u32 xb[L];
+      store_be<L>(xb, x);
+      Fe fx, rhs, y, ny;
+      C::fe_load(fx, xb);
+      C::curve_rhs(rhs, fx);
+      const bool has = C::fe_sqrt(y, rhs);
+      C::fe_neg(ny, y);
+      const bool odd = C::fe_is_odd(y);
+      C::fe_select(y, odd == ((recid[i] & 1) != 0), y, ny);
+      g = g && has;
+      if (!g) { C::fe_zero(fx); C::fe_zero(y); mp_zero<L>(r); r[0] = 1; }
+      C::fe_store(r_xy + i * 2 * L, fx);
+      C::fe_store(r_xy + i * 2 * L + L, y);
+      smont::to_mont<O>(w[b], r);
+      good |= (g ? 1u : 0u) << b;
+      cnt = b + 1;
+    }
+    batch_invert<O, BATCH>(w, cnt);                  // r^-1, Montgomery form
+#pragma unroll 1
+    for (int b = 0; b < cnt; b++) {
+      const size_t i = base + (size_t)b * T;
+      u32 e[L], s[L], a[L], c[L], ord[L];
+      load_be<L>(e, z + i * L);
+      smont::reduce_once<O>(e);
+      load_be<L>(s, sig + i * 2 * L + L);
+      const bool g = (good >> b) & 1u;
+      if (!g) { mp_zero<L>(e); mp_zero<L>(s); }
+      smont::mul<O>(a, e, w[b]);                      // z r^-1
+      smont::order<O>(ord);
+      if (!mp_is_zero<L>(a)) mp_sub<L>(a, ord, a);    // u1 = -(z r^-1)
+      smont::mul<O>(c, s, w[b]);                      // u2 = s r^-1
+      store_be<L>(u1 + i * L, a);
+      store_be<L>(u2 + i * L, c);
+      ok[i] = g ? 1 : 0;
+    }
+  }
+}
+
+// out = A + B in affine coordinates, one field inversion per BATCH elements; ok[i] = 0 (and zeros) for the identity
+template <class C, int BATCH>
+__global__ void __launch_bounds__(256) recover_finish_kernel(const u32* a_xy, const uint8_t* a_inf, const u32* b_xy, const uint8_t* b_inf, u32* out_xy,
+                                                             uint8_t* ok, size_t n) {
+  using Fe = typename C::Fe;
+  constexpr int L = C::NW;
+  Fe pre[BATCH];
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t base = tid; base < n; base += T * BATCH) {
+    u32 kinds = 0;          // 0 = identity / rejected, 1 = one operand is the identity, 2 = chord or tangent
+    int cnt = 0;
+    Fe acc; C::fe_one(acc);
+#pragma unroll 1
+    for (int b = 0; b < BATCH; b++) {
+      const size_t i = base + (size_t)b * T;
+      if (i >= n) break;
+      cnt = b + 1;
+      pre[b] = acc;
+      if (!ok[i]) continue;
+      const bool ai = a_inf[i] != 0, bi = b_inf[i] != 0;
+      if (ai && bi) continue;
+      if (ai || bi) { kinds |= 1u << (2 * b); continue; }
+      const u32* pa = a_xy + i * 2 * L;
+      const u32* pb = b_xy + i * 2 * L;
+      bool same_x = true, same_y = true;
+#pragma unroll
+      for (int j = 0; j < L; j++) { same_x &= (pa[j] == pb[j]); same_y &= (pa[L + j] == pb[L + j]); }
+      if (same_x && !same_y) continue;
+      Fe d, t;
+      if (same_x) { C::fe_load(t, pa + L); C::fe_add(d, t, t); }
+      else { Fe xa, xb; C::fe_load(xa, pa); C::fe_load(xb, pb); C::fe_sub(d, xb, xa); }
+      kinds |= 2u << (2 * b);
+      C::fe_mul(acc, acc, d);
+    }
+    Fe inv_all;
+    C::fe_inv(inv_all, acc);
+#pragma unroll 1
+    for (int b = cnt - 1; b >= 0; b--) {
+      const size_t i = base + (size_t)b * T;
+      const u32 kind = (kinds >> (2 * b)) & 3u;
+      const u32* pa = a_xy + i * 2 * L;
+      const u32* pb = b_xy + i * 2 * L;
+      Fe x3, y3;
+      C::fe_zero(x3); C::fe_zero(y3);
+      if (kind == 1) {
+        const u32* src = a_inf[i] ? pb : pa;
+        C::fe_load(x3, src);
+        C::fe_load(y3, src + L);
+      } else if (kind == 2) {
+        Fe xa, ya, xb, yb, N, D, di, lam, t;
+        C::fe_load(xa, pa); C::fe_load(ya, pa + L);
+        C::fe_load(xb, pb); C::fe_load(yb, pb + L);
+        bool same_x = true;
+#pragma unroll
+        for (int j = 0; j < L; j++) same_x &= (pa[j] == pb[j]);
+        if (same_x) {
+          C::fe_sqr(t, xa);
+          if (!C::A_IS_ZERO) { Fe one; C::fe_one(one); C::fe_sub(t, t, one); }
+          C::fe_add(N, t, t); C::fe_add(N, N, t);
+          C::fe_add(D, ya, ya);
+        } else {
+          C::fe_sub(N, yb, ya);
+          C::fe_sub(D, xb, xa);
+        }
+        C::fe_mul(di, inv_all, pre[b]);
+        C::fe_mul(inv_all, inv_all, D);
+        C::fe_mul(lam, N, di);
+        C::fe_sqr(x3, lam);
+        C::fe_sub(x3, x3, xa); C::fe_sub(x3, x3, xb);
+        C::fe_sub(t, xa, x3);
+        C::fe_mul(y3, lam, t);
+        C::fe_sub(y3, y3, ya);
+      }
+      C::fe_store(out_xy + i * 2 * L, x3);
+      C::fe_store(out_xy + i * 2 * L + L, y3);
+      ok[i] = kind ? 1 : 0;
+    }
+  }
+}
+
 }  // namespace ecdsa
 }  // namespace ecgpu

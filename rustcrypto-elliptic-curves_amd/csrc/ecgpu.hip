@@ -452,6 +452,31 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* c, int curve, const uint8_t* prehash, co
   if ((rc = buf_finish(c, bo))) return rc;
   return finish_host(c, mem);
 }
+int ecgpu_ecdsa_recover_batch(ecgpu_ctx* c, int curve, const uint8_t* prehash, const uint8_t* sig_rs, const uint8_t* recovery_id,
+                              uint8_t* pubkeys_xy, uint8_t* ok, size_t n, int mem, unsigned flags) {
+  if (!c || !prehash || !sig_rs || !recovery_id || !pubkeys_xy || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (n == 0) return ECGPU_OK;
+  ENTER(c, curve);
+  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
+    const PipeArg args[5] = {{prehash, nullptr, nb}, {sig_rs, nullptr, 2 * nb}, {recovery_id, nullptr, 1}, {nullptr, pubkeys_xy, 2 * nb}, {nullptr, ok, 1}};
+    return host_pipeline(c, args, 5, n, [&](void** d, size_t cnt) {
+      return ops->ecdsa_recover(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (const uint8_t*)d[2], (uint32_t*)d[3], (uint8_t*)d[4], cnt, flags);
+    });
+  }
+  Buf bz, bs, br, bq, bo;
+  int rc;
+  if ((rc = buf_in(c, bz, 0, prehash, n * nb, mem))) return rc;
+  if ((rc = buf_in(c, bs, 1, sig_rs, n * 2 * nb, mem))) return rc;
+  if ((rc = buf_in(c, br, 4, recovery_id, n, mem))) return rc;
+  if ((rc = buf_out(c, bq, 2, pubkeys_xy, n * 2 * nb, mem))) return rc;
+  if ((rc = buf_out(c, bo, 3, ok, n, mem))) return rc;
+  if ((rc = ops->ecdsa_recover(c, (const uint32_t*)bz.dev, (const uint32_t*)bs.dev, (const uint8_t*)br.dev, (uint32_t*)bq.dev, (uint8_t*)bo.dev, n,
+                               flags)))
+    return rc;
+  if ((rc = buf_finish(c, bq))) return rc;
+  if ((rc = buf_finish(c, bo))) return rc;
+  return finish_host(c, mem);
+}
 int ecgpu_schnorr_verify_batch(ecgpu_ctx* c, int curve, const uint8_t* pubkeys_x, const uint8_t* sig_rs, const uint8_t* challenges, uint8_t* ok,
                                size_t n, int mem) {
   if (!c || !pubkeys_x || !sig_rs || !challenges || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");

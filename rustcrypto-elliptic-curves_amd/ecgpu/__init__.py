@@ -81,6 +81,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.ecgpu_to_bytes_batch.argtypes = [vp, i, u8p, i, u8p, sz, i]
     lib.ecgpu_from_bytes_batch.argtypes = [vp, i, u8p, u8p, u8p, sz, i]
     lib.ecgpu_ecdsa_verify_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
+    lib.ecgpu_ecdsa_recover_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
     lib.ecgpu_schnorr_verify_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i]
     lib.ecgpu_ecdsa_sign_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
     lib.ecgpu_synth_scalars.argtypes = [vp, i, ctypes.c_uint64, ctypes.c_uint64, u8p, sz]
@@ -102,7 +103,7 @@ EXPORTED_SYMBOLS = (
     "ecgpu_point_add_mixed_batch", "ecgpu_point_double_batch", "ecgpu_batch_normalize", "ecgpu_mul_batch",
     "ecgpu_lincomb_batch", "ecgpu_msm", "ecgpu_validate_scalars", "ecgpu_validate_points", "ecgpu_decompress_batch",
     "ecgpu_synth_scalars", "ecgpu_synth_points", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_sign_batch",
-    "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch",
+    "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch", "ecgpu_ecdsa_recover_batch",
 )
 
 
@@ -328,6 +329,18 @@ class Curve:
         fl = self.default_ecdsa_flags() if flags is None else flags
         self.ctx.check(self.ctx.lib.ecgpu_ecdsa_verify_batch(self.ctx.handle, self.id, _ptr(d_prehash)[0], _ptr(d_sig_rs)[0], _ptr(d_pubkeys_xy)[0],
                                                              _ptr(d_ok)[0], n, DEVICE, fl))
+
+    def ecdsa_recover(self, prehash, sig_rs, recovery_id, flags: Optional[int] = None):
+        """VerifyingKey::recover_from_prehash for a batch -> (pubkeys_xy, ok)"""
+        z, sg = _as_host(prehash, self.nb), _as_host(sig_rs, 2 * self.nb)
+        rid = np.ascontiguousarray(recovery_id, dtype=np.uint8).reshape(-1)
+        if not (len(z) == len(sg) == len(rid)):
+            raise ValueError("prehash, signature and recovery-id batches differ in length")
+        out, ok = _host_out(len(z), 2 * self.nb), np.zeros(len(z), dtype=np.uint8)
+        fl = self.default_ecdsa_flags() if flags is None else flags
+        self.ctx.check(self.ctx.lib.ecgpu_ecdsa_recover_batch(self.ctx.handle, self.id, _ptr(z)[0], _ptr(sg)[0], _ptr(rid)[0], _ptr(out)[0], _ptr(ok)[0],
+                                                              len(z), HOST, fl))
+        return out, ok
 
     def schnorr_verify(self, pubkeys_x, sig_rs, challenges) -> np.ndarray:
         """EC part of BIP340 verification; challenges = tagged challenge hashes (ecgpu.schnorr computes them)."""

@@ -140,6 +140,20 @@ def bip340_vectors():
     return {"sign": sign, "verify": verify}
 
 
+def recovery_vectors():
+    """k256/src/ecdsa.rs:277-298: compressed public key, message, signature, recovery id (y_is_odd, x_reduced)."""
+    t = read("k256/src/ecdsa.rs")
+    t = t[t.index("const RECOVERY_TEST_VECTORS"):t.index("fn public_key_recovery")]
+    out = []
+    for blk in t.split("RecoveryTestVector {")[1:]:
+        pk = re.search(r'pk:\s*hex!\("([0-9a-fA-F]+)"\)', blk).group(1)
+        msg = re.search(r'msg:\s*b"([^"]*)"', blk).group(1)
+        sig = re.sub(r"[^0-9A-Fa-f]", "", re.search(r"sig:\s*hex!\(\s*((?:\"[^\"]*\"\s*)+)\)", blk).group(1))
+        rid = re.search(r"RecoveryId::new\((true|false),\s*(true|false)\)", blk)
+        out.append({"pk": pk.lower(), "msg": msg, "sig": sig.lower(), "recid": (1 if rid.group(1) == "true" else 0) | (2 if rid.group(2) == "true" else 0)})
+    return out
+
+
 def h2c_vectors(curve):
     t = read(f"{curve}/src/arithmetic/hash2curve.rs")
     i = t.index("const TEST_VECTORS")
@@ -186,6 +200,7 @@ def main():
     for c in ("k256", "p256", "p384"):
         fx[c] = {"group": group_vectors(c), "ecdsa": ecdsa_vectors(c), "hash2curve": h2c_vectors(c), "encoding": encoding_vectors(c)}
     fx["k256"]["bip340"] = bip340_vectors()
+    fx["k256"]["recovery"] = recovery_vectors()
     fx["k256"]["field_dbl"] = field_dbl("k256")
     fx["p256"]["field_dbl"] = field_dbl("p256")
     fx["k256"]["field_kat"] = risc0_field_kats()

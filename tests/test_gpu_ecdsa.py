@@ -211,3 +211,53 @@ def test_bip340_schnorr_vectors_and_random(ctx, ref_vectors):
         assert bool(got[i]) == w, (i, i % 9)
         good += w
     assert 50 < good < n
+
+
+@pytest.mark.parametrize("cn", CURVES)
+def test_public_key_recovery(ctx, cn, ref_vectors):
+    """recover_from_prehash: the reference's two secp256k1 vectors, then sign -> recover == d G on random batches of
+    every curve, wrong recovery ids, corrupted signatures and out-of-range values against the model."""
+    c = M.CURVES[cn]
+    cv = ctx.curve(cn)
+    nb = c.nbytes
+    tob = lambda v: v.to_bytes(nb, "big")
+    if cn == "k256":
+        vs = ref_vectors["k256"]["recovery"]
+        z = b"".join(hashlib.sha256(v["msg"].encode()).digest() for v in vs)
+        out, ok = cv.ecdsa_recover(z, b"".join(bytes.fromhex(v["sig"]) for v in vs), [v["recid"] for v in vs])
+        assert ok.all()
+        assert [bytes(g).hex() for g in cv.to_bytes(out)] == [v["pk"] for v in vs]
+    rng = random.Random(4321 + nb)
+    n = 400
+    ds = [rng.randrange(1, c.n) for _ in range(n)]
+    ks = [rng.randrange(1, c.n) for _ in range(n)]
+    zs = [rng.randbytes(nb) for _ in range(n)]
+    sig, rec, okv = cv.ecdsa_sign(b"".join(map(tob, ds)), b"".join(map(tob, ks)), b"".join(zs))
+    assert okv.all()
+    keys, _ = cv.mul_by_generator(b"".join(map(tob, ds)))
+    out, ok = cv.ecdsa_recover(b"".join(zs), sig, rec)
+    assert ok.all() and bytes(out) == bytes(keys)
+    sigs = [bytes(sig[i]) for i in range(n)]
+    rid = [int(x) for x in rec]
+    for i in range(n):
+        m = i % 8
+        r = int.from_bytes(sigs[i][:nb], "big"); s = int.from_bytes(sigs[i][nb:], "big")
+        if m == 0: rid[i] ^= 1
+        elif m == 1: rid[i] |= 2                    # r + n: almost always >= p or not on the curve
+        elif m == 2: s = c.n - s                    # high s: refused on k256, a different key elsewhere
+        elif m == 3: r = 0
+        elif m == 4: s = c.n
+        elif m == 5: zs[i] = rng.randbytes(nb)
+        elif m == 6: rid[i] = 4
+        sigs[i] = tob(r) + tob(s)
+    out, ok = cv.ecdsa_recover(b"".join(zs), b"".join(sigs), rid)
+    hits = 0
+    for i in range(n):
+        r = int.from_bytes(sigs[i][:nb], "big"); s = int.from_bytes(sigs[i][nb:], "big")
+        Q = M.ecdsa_recover_prehashed(c, zs[i], r, s, rid[i], reject_high_s=(cn == "k256"))
+        if Q is None:
+            assert ok[i] == 0 and not bytes(out[i]).strip(b"\0"), (i, i % 8)
+        else:
+            assert ok[i] == 1 and bytes(out[i]) == tob(Q[0]) + tob(Q[1]), (i, i % 8)
+            hits += 1
+    assert 100 < hits < n

@@ -106,3 +106,12 @@ def test_bip340_vectors_pin_the_schnorr_model(ref_vectors):
         assert M.schnorr_verify_prehash(px, bytes.fromhex(s["message"]), sig)
     for t in v["verify"]:
         assert M.schnorr_verify_prehash(bytes.fromhex(t["public_key"]), bytes.fromhex(t["message"]), bytes.fromhex(t["signature"])) == t["valid"], t["index"]
+
+
+def test_recovery_vectors_pin_the_model(ref_vectors):
+    c = M.K256
+    for v in ref_vectors["k256"]["recovery"]:
+        z = hashlib.sha256(v["msg"].encode()).digest()
+        sig = bytes.fromhex(v["sig"])
+        Q = M.ecdsa_recover_prehashed(c, z, int.from_bytes(sig[:32], "big"), int.from_bytes(sig[32:], "big"), v["recid"], reject_high_s=True)
+        assert M.group_to_bytes(c, Q).hex() == v["pk"]
