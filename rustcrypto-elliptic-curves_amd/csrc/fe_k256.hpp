@@ -71,42 +71,6 @@ ECGPU_HD void fold_top_fast(u32* r, u64 T) {
 // r = a * b mod p (weakly reduced).  field_5x52.rs:288-449 (mul_inner) is the reference.
 // Columns 8..14 of the schoolbook product are summed first (H), then columns 0..7 are summed
 // together with H*C, so the pseudo-Mersenne fold rides on the same 96-bit accumulator.
-#ifdef ECGPU_K256_PER_MAC_ASM
-ECGPU_HD void mul(FeK256& r, const FeK256& a, const FeK256& b) {
-  u32 h[8];
-  Acc96 c{0, 0};
-#pragma unroll
-  for (int k = 8; k < 15; k++) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int j = k - i;
-      if (j >= 0 && j < 8) {
-        if (k == 14) mac_nc(c, a.v[i], b.v[j]); else mac(c, a.v[i], b.v[j]);
-      }
-    }
-    h[k - 8] = acc_pop(c);
-  }
-  h[7] = (u32)c.lo;
-  u32 t[8];
-  c.lo = 0; c.hi = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int j = k - i;
-      if (j >= 0 && j < 8) mac(c, a.v[i], b.v[j]);
-    }
-    mac(c, h[k], C_LO);
-    if (k > 0) acc_add32(c, h[k - 1]);
-    t[k] = acc_pop(c);
-  }
-  // overflow above 2^256: remaining accumulator plus the last shifted word of H
-  const u64 T = c.lo + h[7];
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = t[i];
-  fold_top(r.v, T);
-}
-#else
 // One asm statement per column (hipcc pads each asm statement with an s_nop): the column's
 // products, and for the low half also h[k]*977 and h[k-1]*1, go into a single statement.
 template <int K>
@@ -141,7 +105,6 @@ ECGPU_HD void mul(FeK256& r, const FeK256& a, const FeK256& b) {
   const u64 T = c.lo + h[7] + cy;
   fold_top_fast(r.v, T);
 }
-#endif
 
 // reduce a 16-word integer modulo p: lo + hi * 977 + (hi << 32), then fold what spills over 2^256
 ECGPU_HD void reduce16(FeK256& r, const u32* w) {

@@ -140,25 +140,6 @@ ECGPU_HD void mac(Acc96& c, u32 a, u32 b) {
 }
 // c += a * b where the caller guarantees the low 64 bits cannot overflow
 ECGPU_HD void mac_nc(Acc96& c, u32 a, u32 b) { c.lo += (u64)a * b; }
-// c += 2 * a * b
-ECGPU_HD void mac2(Acc96& c, u32 a, u32 b) {
-  mac(c, a, b);
-  mac(c, a, b);
-}
-// c += w (a 32-bit word)
-ECGPU_HD void acc_add32(Acc96& c, u32 w) {
-#if ECGPU_ASM
-  // a*1 + c: one mad + one addc, cheaper than a three-instruction carry chain
-  asm volatile("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(c.lo), "+v"(c.hi)
-      : "v"(w)
-      : "vcc");
-#else
-  c.lo += w;
-  c.hi += (c.lo < w);
-#endif
-}
-
 // c -= w, the accumulator read as a 96-bit two's-complement number
 ECGPU_HD void acc_sub32(Acc96& c, u32 w) {
   u32 l0 = (u32)c.lo, l1 = (u32)(c.lo >> 32), bw = 0;
