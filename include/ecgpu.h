@@ -211,6 +211,13 @@ int ecgpu_ecdsa_recover_batch(ecgpu_ctx* ctx, int curve, const uint8_t* prehash,
 int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* pubkeys_x, const uint8_t* sig_rs,
                                const uint8_t* challenges, uint8_t* ok, size_t n, int mem);
 
+/* ---- hash to curve (RFC 9380 suites *_XMD:SHA-*_SSWU_RO_) ------------------------------------------------------
+ * MapToCurve::map_to_curve and the sum of GroupDigest::hash_from_bytes (k256|p256|p384/src/arithmetic/hash2curve.rs):
+ * u holds n x count field elements (canonical big-endian, already reduced: hash_to_field / FromOkm is host glue);
+ * count = 1: out[i] = map_to_curve(u[i]);  count = 2: out[i] = map_to_curve(u[2i]) + map_to_curve(u[2i+1]). */
+int ecgpu_map_to_curve_batch(ecgpu_ctx* ctx, int curve, const uint8_t* u, int count, uint8_t* out_xy,
+                             uint8_t* out_inf, size_t n, int mem);
+
 /* ---- synthetic inputs for benchmarks (device memory only) ------------------------------------
  * Fill device buffers with the counter-based streams specified in oracle/synth.py:
  * scalars[i] = reduce(stream 0), points[i] = try-and-increment decompress of streams 1.. .

@@ -730,3 +730,97 @@ def ecdsa_recover_prehashed(c: Curve, z: bytes, r: int, s: int, recid: int, reje
     ri = pow(r, -1, n)
     u1, u2 = (-(ri * e)) % n, ri * s % n
     return affine_add(c, affine_mul(c, u1, (c.gx, c.gy)), affine_mul(c, u2, R))
+
+
+# --- hash to curve, RFC 9380 suites *_XMD:SHA-*_SSWU_RO_ (k256|p256|p384/src/arithmetic/hash2curve.rs) --------------
+_H2C = None
+
+
+def _h2c_params(c: Curve):
+    global _H2C
+    if _H2C is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "h2c_params.json")) as f:
+            raw = json.load(f)
+        _H2C = {cn: {k: (int(v, 16) if isinstance(v, str) else ({kk: [int(x, 16) for x in vv] for kk, vv in v.items()} if v else None))
+                     for k, v in d.items()} for cn, d in raw.items()}
+    return _H2C[c.name]
+
+
+def expand_message_xmd(hash_name: str, msg: bytes, dst: bytes, length: int) -> bytes:
+    """RFC 9380 5.3.1 (ExpandMsgXmd of the external elliptic-curve crate)."""
+    import hashlib
+    h = lambda b: hashlib.new(hash_name, b).digest()
+    b_in, s_in = hashlib.new(hash_name).digest_size, hashlib.new(hash_name).block_size
+    ell = -(-length // b_in)
+    assert ell <= 255 and len(dst) <= 255
+    dst_prime = dst + bytes([len(dst)])
+    b0 = h(bytes(s_in) + msg + length.to_bytes(2, "big") + b"\x00" + dst_prime)
+    b = [h(b0 + b"\x01" + dst_prime)]
+    for i in range(2, ell + 1):
+        b.append(h(bytes(x ^ y for x, y in zip(b0, b[-1])) + bytes([i]) + dst_prime))
+    return b"".join(b)[:length]
+
+
+def h2c_hash_name(c: Curve) -> str:
+    return "sha384" if c.name == "p384" else "sha256"
+
+
+def hash_to_field(c: Curve, msg: bytes, dst: bytes, count: int = 2):
+    """FromOkm: L = 48 bytes (72 for p384) per element, big-endian integer mod p (hash2curve.rs: from_okm)."""
+    L = 72 if c.name == "p384" else 48
+    u = expand_message_xmd(h2c_hash_name(c), msg, dst, count * L)
+    return [int.from_bytes(u[L * i:L * (i + 1)], "big") % c.p for i in range(count)]
+
+
+def osswu(c: Curve, u: int):
+    """Simplified SWU for p = 3 (mod 4), the straight-line form of k256/src/arithmetic/hash2curve.rs:100-143;
+    returns (x, y) on the curve y^2 = x^3 + A x + B of the suite (E' for secp256k1)."""
+    P = _h2c_params(c)
+    p, Z, A, B, c2 = c.p, P["z"], P["a"], P["b"], P["c2"]
+    tv1 = u * u % p
+    tv3 = Z * tv1 % p
+    tv2 = tv3 * tv3 % p
+    xd = (tv2 + tv3) % p
+    x1n = B * (xd + 1) % p
+    xd = (-A) * xd % p
+    if xd == 0:
+        xd = Z * A % p
+    tv2 = xd * xd % p
+    gxd = tv2 * xd % p
+    tv2 = A * tv2 % p
+    gx1 = (x1n * ((tv2 + x1n * x1n) % p) + gxd * B) % p
+    tv4 = gxd * gxd % p
+    tv2 = gx1 * gxd % p
+    tv4 = tv4 * tv2 % p
+    y1 = pow(tv4, (p - 3) // 4, p) * tv2 % p
+    x2n = tv3 * x1n % p
+    y2 = y1 * c2 % p * tv1 % p * u % p
+    e2 = (y1 * y1 % p * gxd % p) == gx1
+    x = (x1n if e2 else x2n) * pow(xd, -1, p) % p
+    y = y1 if e2 else y2
+    if (u & 1) != (y & 1):
+        y = (p - y) % p
+    return x, y
+
+
+def h2c_isogeny(c: Curve, x: int, y: int):
+    """3-isogeny E' -> secp256k1 (RFC 9380 E.1; coefficients in ascending powers)."""
+    iso = _h2c_params(c)["iso"]
+    p = c.p
+    ev = lambda co: sum(k * pow(x, i, p) for i, k in enumerate(co)) % p
+    xo = ev(iso["xnum"]) * pow(ev(iso["xden"]), -1, p) % p
+    yo = y * ev(iso["ynum"]) % p * pow(ev(iso["yden"]), -1, p) % p
+    return xo, yo
+
+
+def map_to_curve(c: Curve, u: int):
+    x, y = osswu(c, u)
+    return h2c_isogeny(c, x, y) if _h2c_params(c)["iso"] else (x, y)
+
+
+def hash_to_curve(c: Curve, msg: bytes, dst: bytes):
+    """GroupDigest::hash_from_bytes: Q0 + Q1 (cofactor 1)."""
+    u0, u1 = hash_to_field(c, msg, dst, 2)
+    return affine_add(c, map_to_curve(c, u0), map_to_curve(c, u1))

@@ -7,6 +7,7 @@
 #include "ecdsa_kernels.hpp"
 #include "sec1_kernels.hpp"
 #include "schnorr_kernels.hpp"
+#include "h2c_kernels.hpp"
 
 namespace ecgpu {
 
@@ -223,6 +224,11 @@ struct CurveOps {
     HIPCHK(c, hipGetLastError());
     return 0;
   }
+  static int h2c_map(ecgpu_ctx* c, const u32* u, int count, u32* out_xy, uint8_t* out_inf, size_t n) {
+    hipLaunchKernelGGL((h2c::map_kernel<C>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, u, count, out_xy, out_inf, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   static int ecdsa_recover(ecgpu_ctx* c, const u32* z, const u32* sig, const uint8_t* recid, u32* out_xy, uint8_t* ok, size_t n, unsigned flags) {
     const size_t sz_s = al256(n * C::NB), sz_p = al256(n * 2 * C::NB), sz_f = al256(n);
     int rc = ecdsa_reserve(c, 2 * sz_s + 3 * sz_p + 2 * sz_f);
@@ -286,7 +292,7 @@ struct CurveOps {
   }
   static const ecgpu_curve_ops* table() {
     static const ecgpu_curve_ops t = {field_op, point_op, normalize, lincomb, msm, validate_scalars, validate_points,
-                                      decompress, synth_scalars, synth_points, to_bytes, from_bytes, ecdsa_verify, ecdsa_recover, schnorr_verify, ecdsa_sign};
+                                      decompress, synth_scalars, synth_points, to_bytes, from_bytes, ecdsa_verify, h2c_map, ecdsa_recover, schnorr_verify, ecdsa_sign};
     return &t;
   }
 };

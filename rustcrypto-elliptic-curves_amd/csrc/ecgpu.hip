@@ -452,6 +452,21 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* c, int curve, const uint8_t* prehash, co
   if ((rc = buf_finish(c, bo))) return rc;
   return finish_host(c, mem);
 }
+int ecgpu_map_to_curve_batch(ecgpu_ctx* c, int curve, const uint8_t* u, int count, uint8_t* out_xy, uint8_t* out_inf, size_t n, int mem) {
+  if (!c || !u || !out_xy) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (count != 1 && count != 2) return ecgpu_set_err(c, ECGPU_ERR_ARG, "count must be 1 (map_to_curve) or 2 (hash_to_curve: Q0 + Q1)");
+  if (n == 0) return ECGPU_OK;
+  ENTER(c, curve);
+  Buf bu, bo, bi;
+  int rc;
+  if ((rc = buf_in(c, bu, 0, u, n * count * nb, mem))) return rc;
+  if ((rc = buf_out(c, bo, 2, out_xy, n * 2 * nb, mem))) return rc;
+  if ((rc = buf_out(c, bi, 3, out_inf, n, mem))) return rc;
+  if ((rc = ops->h2c_map(c, (const uint32_t*)bu.dev, count, (uint32_t*)bo.dev, (uint8_t*)bi.dev, n))) return rc;
+  if ((rc = buf_finish(c, bo))) return rc;
+  if ((rc = buf_finish(c, bi))) return rc;
+  return finish_host(c, mem);
+}
 int ecgpu_ecdsa_recover_batch(ecgpu_ctx* c, int curve, const uint8_t* prehash, const uint8_t* sig_rs, const uint8_t* recovery_id,
                               uint8_t* pubkeys_xy, uint8_t* ok, size_t n, int mem, unsigned flags) {
   if (!c || !prehash || !sig_rs || !recovery_id || !pubkeys_xy || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");

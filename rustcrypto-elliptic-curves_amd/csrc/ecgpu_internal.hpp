@@ -81,6 +81,7 @@ struct ecgpu_curve_ops {
   int (*to_bytes)(ecgpu_ctx* c, const uint32_t* pts, int pt_fmt, uint8_t* out, size_t n);
   int (*from_bytes)(ecgpu_ctx* c, const uint8_t* in, uint32_t* out_xy, uint8_t* ok, size_t n);
   int (*ecdsa_verify)(ecgpu_ctx* c, const uint32_t* z, const uint32_t* sig, const uint32_t* q_xy, uint8_t* ok, size_t n, unsigned flags);
+  int (*h2c_map)(ecgpu_ctx* c, const uint32_t* u, int count, uint32_t* out_xy, uint8_t* out_inf, size_t n);
   int (*ecdsa_recover)(ecgpu_ctx* c, const uint32_t* z, const uint32_t* sig, const uint8_t* recid, uint32_t* out_xy, uint8_t* ok, size_t n,
                        unsigned flags);
   int (*schnorr_verify)(ecgpu_ctx* c, const uint32_t* px, const uint32_t* sig, const uint32_t* e, uint8_t* ok, size_t n);

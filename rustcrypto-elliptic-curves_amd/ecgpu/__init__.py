@@ -81,6 +81,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.ecgpu_to_bytes_batch.argtypes = [vp, i, u8p, i, u8p, sz, i]
     lib.ecgpu_from_bytes_batch.argtypes = [vp, i, u8p, u8p, u8p, sz, i]
     lib.ecgpu_ecdsa_verify_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
+    lib.ecgpu_map_to_curve_batch.argtypes = [vp, i, u8p, i, u8p, u8p, sz, i]
     lib.ecgpu_ecdsa_recover_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
     lib.ecgpu_schnorr_verify_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i]
     lib.ecgpu_ecdsa_sign_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, u8p, u8p, sz, i, ctypes.c_uint]
@@ -103,7 +104,7 @@ EXPORTED_SYMBOLS = (
     "ecgpu_point_add_mixed_batch", "ecgpu_point_double_batch", "ecgpu_batch_normalize", "ecgpu_mul_batch",
     "ecgpu_lincomb_batch", "ecgpu_msm", "ecgpu_validate_scalars", "ecgpu_validate_points", "ecgpu_decompress_batch",
     "ecgpu_synth_scalars", "ecgpu_synth_points", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_sign_batch",
-    "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch", "ecgpu_ecdsa_recover_batch",
+    "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch", "ecgpu_ecdsa_recover_batch", "ecgpu_map_to_curve_batch",
 )
 
 
@@ -329,6 +330,14 @@ class Curve:
         fl = self.default_ecdsa_flags() if flags is None else flags
         self.ctx.check(self.ctx.lib.ecgpu_ecdsa_verify_batch(self.ctx.handle, self.id, _ptr(d_prehash)[0], _ptr(d_sig_rs)[0], _ptr(d_pubkeys_xy)[0],
                                                              _ptr(d_ok)[0], n, DEVICE, fl))
+
+    def map_to_curve(self, u, count: int = 1):
+        """MapToCurve::map_to_curve (count = 1) or Q0 + Q1 of hash_from_bytes (count = 2) -> (points_xy, inf)"""
+        uu = _as_host(u, self.nb)
+        n = len(uu) // count
+        out, inf = _host_out(n, 2 * self.nb), np.zeros(n, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ecgpu_map_to_curve_batch(self.ctx.handle, self.id, _ptr(uu)[0], count, _ptr(out)[0], _ptr(inf)[0], n, HOST))
+        return out, inf
 
     def ecdsa_recover(self, prehash, sig_rs, recovery_id, flags: Optional[int] = None):
         """VerifyingKey::recover_from_prehash for a batch -> (pubkeys_xy, ok)"""

@@ -155,14 +155,20 @@ def recovery_vectors():
 
 
 def h2c_vectors(curve):
+    """RFC 9380 vectors of <curve>/src/arithmetic/hash2curve.rs: message, u_0, u_1 (hash_to_field), Q0 = map(u_0),
+    Q1 = map(u_1), P = Q0 + Q1; the domain separation tag is kept with them."""
     t = read(f"{curve}/src/arithmetic/hash2curve.rs")
+    dst = re.search(r'const DST: &\[u8\] = b"([^"]*)"', t).group(1)
     i = t.index("const TEST_VECTORS")
     out = []
     for blk in t[i:].split("TestVector {")[1:]:
         fields = dict(re.findall(r'(\w+):\s*hex!\(\s*"([0-9A-Fa-f]+)"\s*\)', blk))
         if "q0_x" not in fields:
             continue
-        out.append({k: fields[k] for k in ("p_x", "p_y", "q0_x", "q0_y", "q1_x", "q1_y")})
+        v = {k: fields[k] for k in ("p_x", "p_y", "u_0", "u_1", "q0_x", "q0_y", "q1_x", "q1_y")}
+        v["msg"] = re.search(r'msg:\s*b"([^"]*)"', blk).group(1)
+        v["dst"] = dst
+        out.append(v)
     return out
 
 

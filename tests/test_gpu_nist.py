@@ -279,3 +279,39 @@ def test_group_encoding_to_from_bytes(ctx, cn, ref_vectors):
         assert bool(ok[i]) == w_ok, (i, e.hex())
         exp = bytes(2 * nb) if (P is None) else M.i2b(c, P[0]) + M.i2b(c, P[1])
         assert bytes(out[i]) == exp, (i, e.hex())
+
+
+@pytest.mark.parametrize("cn", ["k256", "p256", "p384"])
+def test_hash_to_curve(ctx, cn, ref_vectors):
+    """map_to_curve and hash_from_bytes: the RFC 9380 vectors of <curve>/src/arithmetic/hash2curve.rs (u -> Q0, Q1,
+    msg -> P), then random and edge field elements (0, 1, p - 1, values making the first candidate a non-square)
+    against the model."""
+    import random
+    from ecgpu import hash2curve
+    c = M.CURVES[cn]
+    cv = ctx.curve(cn)
+    vs = ref_vectors[cn]["hash2curve"]
+    dst = vs[0]["dst"].encode()
+    u = b"".join(bytes.fromhex(v["u_0"]) + bytes.fromhex(v["u_1"]) for v in vs)
+    q, inf = cv.map_to_curve(u, count=1)
+    assert not inf.any()
+    for i, v in enumerate(vs):
+        assert bytes(q[2 * i]).hex() == v["q0_x"] + v["q0_y"] and bytes(q[2 * i + 1]).hex() == v["q1_x"] + v["q1_y"]
+    pts, inf = hash2curve.hash_from_bytes(cv, [v["msg"].encode() for v in vs], dst)
+    assert [bytes(p).hex() for p in pts] == [v["p_x"] + v["p_y"] for v in vs] and not inf.any()
+    assert hash2curve.hash_to_field(cv, b"abc", dst).hex() == vs[1]["u_0"] + vs[1]["u_1"]
+    rng = random.Random(9380)
+    us = [0, 1, 2, c.p - 1, c.p - 2] + [rng.randrange(c.p) for _ in range(200)]
+    got, _ = cv.map_to_curve(b"".join(M.i2b(c, x) for x in us), count=1)
+    for x, g in zip(us, got):
+        Q = M.map_to_curve(c, x)
+        assert M.on_curve(c, Q) and bytes(g) == M.i2b(c, Q[0]) + M.i2b(c, Q[1]), x
+    pairs = [(us[i], us[i + 1]) for i in range(0, 100, 2)] + [(7, 7), (9, c.p - 9)]      # equal points; u and -u map to P and -P
+    got, inf = cv.map_to_curve(b"".join(M.i2b(c, a) + M.i2b(c, b) for a, b in pairs), count=2)
+    for (a, b), g, f in zip(pairs, got, inf):
+        S = M.affine_add(c, M.map_to_curve(c, a), M.map_to_curve(c, b))
+        if S is None:
+            assert f == 1 and not bytes(g).strip(b"\0")
+        else:
+            assert f == 0 and bytes(g) == M.i2b(c, S[0]) + M.i2b(c, S[1])
+    assert inf[-1] == 1

@@ -185,3 +185,17 @@ def test_sec1_encoding_vectors(cn, ref_vectors):
         assert ok and b"\x04" + M.i2b(c, P[0]) + M.i2b(c, P[1]) == bytes.fromhex(e["uncompact_basepoint"])
     assert M.group_from_bytes(c, b"\x04" + bytes(c.nbytes))[0] is False
     assert M.group_from_bytes(c, b"\x00" + b"\x01" * c.nbytes)[0] is False
+
+
+@pytest.mark.parametrize("cn", ["k256", "p256", "p384"])
+def test_hash_to_curve_vectors_pin_the_model(cn, ref_vectors):
+    """RFC 9380 vectors held by <curve>/src/arithmetic/hash2curve.rs: msg -> u -> Q0, Q1 -> P."""
+    c = M.CURVES[cn]
+    vs = ref_vectors[cn]["hash2curve"]
+    assert len(vs) == 5
+    for v in vs:
+        u0, u1 = M.hash_to_field(c, v["msg"].encode(), v["dst"].encode())
+        assert (u0, u1) == (int(v["u_0"], 16), int(v["u_1"], 16))
+        assert M.map_to_curve(c, u0) == (int(v["q0_x"], 16), int(v["q0_y"], 16))
+        assert M.map_to_curve(c, u1) == (int(v["q1_x"], 16), int(v["q1_y"], 16))
+        assert M.hash_to_curve(c, v["msg"].encode(), v["dst"].encode()) == (int(v["p_x"], 16), int(v["p_y"], 16))
