@@ -177,6 +177,32 @@ ECGPU_HD void neg(FeK256& r, const FeK256& a) {
 }
 ECGPU_HD void dbl(FeK256& r, const FeK256& a) { add(r, a, a); }
 
+// r = a * 2^K mod p for K = 1, 2, 3: a funnel shift of the eight words and a fold of the K bits shifted out of the
+// top (8 shifts + 3 carry instructions instead of K carry chains of ten).  r may alias a.
+template <int K>
+ECGPU_HD void shl(FeK256& r, const FeK256& a) {
+  static_assert(K >= 1 && K <= 3, "small shifts only");
+  const u32 top = a.v[7] >> (32 - K);
+  u32 t[8];
+#pragma unroll
+  for (int i = 7; i >= 1; i--) t[i] = (a.v[i] << K) | (a.v[i - 1] >> (32 - K));
+  t[0] = a.v[0] << K;
+  // + top * C with C = 2^32 + 977: top * 977 < 2^13 into word 0, top into word 1
+  u32 c = 0;
+  r.v[0] = addc(t[0], top * C_LO, c);
+  r.v[1] = addc(t[1], top, c);
+#pragma unroll
+  for (int i = 2; i < 8; i++) r.v[i] = t[i];
+  if (__builtin_expect(c != 0, 0)) {
+#pragma unroll
+    for (int i = 2; i < 8; i++) r.v[i] = addc(r.v[i], 0u, c);
+    u32 c2 = 0;                       // wrapped past 2^256: the value is then tiny, one more fold cannot carry far
+    r.v[0] = addc(r.v[0], c ? C_LO : 0u, c2);
+    r.v[1] = addc(r.v[1], c, c2);
+    r.v[2] = addc(r.v[2], 0u, c2);
+  }
+}
+
 // r = a * k for a small constant (field_5x52.rs:276-285 mul_single)
 ECGPU_HD void mul_small(FeK256& r, const FeK256& a, u32 k) {
   u64 acc = 0;

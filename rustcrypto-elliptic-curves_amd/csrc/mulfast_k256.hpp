@@ -40,14 +40,14 @@ ECGPU_HD void jac_double(JacK256& p) {
   FeK256 a, b, t;
   sqr(a, p.x);
   sqr(b, p.y);
-  mul(p.z, p.y, p.z); dbl(p.z, p.z);        // Z3
-  mul(p.y, p.x, b); dbl(p.y, p.y); dbl(p.y, p.y);   // D (in p.y)
+  mul(p.z, p.y, p.z); shl<1>(p.z, p.z);      // Z3
+  mul(p.y, p.x, b); shl<2>(p.y, p.y);        // D (in p.y)
   sqr(b, b);                                 // C
-  dbl(t, a); add(a, t, a);                   // E (in a)
+  shl<1>(t, a); add(a, t, a);                // E (in a)
   sqr(t, a);
   sub(t, t, p.y); sub(p.x, t, p.y);          // X3 = E^2 - 2D
   sub(p.y, p.y, p.x); mul(p.y, a, p.y);      // E (D - X3)
-  dbl(b, b); dbl(b, b); dbl(b, b);           // 8C
+  shl<3>(b, b);                              // 8C
   sub(p.y, p.y, b);
 }
 ECGPU_HD void jac_double(JacK256& r, const JacK256& p) { r = p; jac_double(r); }

@@ -9,7 +9,7 @@ static void load(FeK256& f, const uint8_t* b) { u32 w[8]; memcpy(w, b, 32); k256
 static void store(uint8_t* b, const FeK256& f) { u32 w[8]; k256::to_be_words(w, f); memcpy(b, w, 32); }
 
 extern "C" {
-// op: 0 mul 1 sqr 2 add 3 sub 4 neg 5 inv 6 sqrt 7 mul_small(b[0..3] LE) 8 normalize-only
+// op: 0 mul 1 sqr 2 add 3 sub 4 neg 5 inv 6 sqrt 7 mul_small(b[0..3] LE) 8 normalize-only 9/10/11 shl<1/2/3>
 // raw=1: inputs are taken as raw 256-bit integers (possibly >= p) and the output is NOT normalised
 int ht_k256_fe_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int raw) {
   for (int i = 0; i < n; i++) {
@@ -25,6 +25,9 @@ int ht_k256_fe_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, int 
       case 6: ok = k256::sqrt(r, x); break;
       case 7: { u32 k; memcpy(&k, b + 32 * i + 28, 4); k256::mul_small(r, x, bswap32(k)); break; }
       case 8: r = x; break;
+      case 9: k256::shl<1>(r, x); break;
+      case 10: k256::shl<2>(r, x); break;
+      case 11: { r = x; k256::shl<3>(r, r); break; }          // aliased
       default: return -1;
     }
     if (!raw) k256::normalize(r, r);

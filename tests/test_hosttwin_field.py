@@ -56,6 +56,16 @@ def test_unary_ops():
         assert g == (-x) % P
     for x, g in zip(xs, run(8, xs)):
         assert g == x % P
+    # funnel-shift multiples by 2, 4, 8 on raw inputs (everything below 2^256 is a valid weak representative),
+    # including the values whose fold carries out of word 1 and past 2^256
+    hard = [2**256 - 1, 2**255, 2**255 + 2**64 - 1, 2**256 - 2**32, (2**256 - 1) ^ (2**64 - 1) | (2**64 - 978), 2**254 + 2**64 - 1,
+            2**253 + 2**64 - 5, P, P - 1, P + 1, 2**256 - 978]
+    for op, k in ((9, 2), (10, 4), (11, 8)):
+        vals = xs + hard
+        for x, g in zip(vals, run(op, vals)):
+            assert g == x * k % P, (op, hex(x))
+        for x, g in zip(vals, run(op, vals, raw=1)):
+            assert g < 2**256 and g % P == x * k % P
     ks = [0, 1, 2, 3, 7, 8, 21, 24, 168, 65535] * 200
     xk = [rng.randrange(2**256) for _ in ks]
     got = run(7, xk, ks)
