@@ -18,12 +18,14 @@ constexpr int C = 16;                         // window bits
 constexpr int NWIN = 17;                      // 16 full windows + the carry of the signed recoding
 constexpr int NBUCKET = 1 << (C - 1);         // |digit| in 1..2^15
 constexpr int SORT_CHUNKS = 15;               // workgroups per window in the counting sort: 17 x 15 = 255, one per CU
-// bucket reduction tree: 2^15 buckets = NSEG1 x SEG1 x SEG0 per window
-constexpr int LOG_SEG0 = 5, SEG0 = 1 << LOG_SEG0;     // buckets per level-0 run
-constexpr int LOG_SEG1 = 5, SEG1 = 1 << LOG_SEG1;     // level-0 results per level-1 run
-constexpr int NSEG0 = NBUCKET / SEG0;                 // level-0 runs per window (1024)
-constexpr int NSEG1 = NSEG0 / SEG1;                   // level-1 runs per window (32)
-constexpr int SUMW_LEN = 32, NSUMW = NSEG0 / SUMW_LEN;  // partial sums of the level-0 weighted parts
+// bucket reduction tree: 2^15 buckets = NSEG1 x SEG1 x SEG0 per window.  Short runs keep the dependent chains of the
+// two segment kernels short (16 and 32 additions); the window kernel finishes with LDS tree sums over NSEG1 lanes.
+constexpr int LOG_SEG0 = 3, SEG0 = 1 << LOG_SEG0;     // buckets per level-0 run
+constexpr int LOG_SEG1 = 4, SEG1 = 1 << LOG_SEG1;     // level-0 results per level-1 run
+constexpr int NSEG0 = NBUCKET / SEG0;                 // level-0 runs per window (4096)
+constexpr int LOG_NSEG1 = C - 1 - LOG_SEG0 - LOG_SEG1;
+constexpr int NSEG1 = 1 << LOG_NSEG1;                 // level-1 runs per window (256)
+constexpr int SUMW_LEN = NSEG0 / NSEG1, NSUMW = NSEG1;  // partial sums of the level-0 weighted parts, one per window-kernel lane
 
 // general Jacobian addition (11M + 5S) with the exceptional cases handled
 ECGPU_HD void jac_add(JacK256& r, const JacK256& p, const JacK256& q) {

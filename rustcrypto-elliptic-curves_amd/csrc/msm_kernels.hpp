@@ -81,14 +81,16 @@ __global__ void __launch_bounds__(256) totals_kernel(const u32* part, u32* hist)
   hist[j] = s;
 }
 
-// 2b. exclusive scan of the bucket totals (one workgroup; 17 * 2^15 counters)
-__global__ void __launch_bounds__(1024) scan_kernel(const u32* hist, u32* offsets, int total) {
+// 2b. exclusive scan of the bucket totals: one workgroup per window scans its 2^15 counters (the window's own offset is
+//     added by scan_base_kernel), so the 17 windows run side by side instead of one workgroup walking all 557 056.
+__global__ void __launch_bounds__(1024) scan_kernel(const u32* hist, u32* offsets, u32* win_total) {
   __shared__ u32 psum[1024];
-  const int t = threadIdx.x;
-  const int per = (total + 1023) / 1024;
-  const int lo = t * per, hi = (lo + per < total) ? lo + per : total;
+  const int w = blockIdx.x, t = threadIdx.x;
+  constexpr int PER = NBUCKET / 1024;
+  const u32* src = hist + (size_t)w * NBUCKET + t * PER;
   u32 s = 0;
-  for (int j = lo; j < hi; j++) s += hist[j];
+#pragma unroll
+  for (int j = 0; j < PER; j++) s += src[j];
   psum[t] = s;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -98,8 +100,20 @@ __global__ void __launch_bounds__(1024) scan_kernel(const u32* hist, u32* offset
     __syncthreads();
   }
   u32 run = (t == 0) ? 0 : psum[t - 1];
-  for (int j = lo; j < hi; j++) { offsets[j] = run; run += hist[j]; }
-  if (t == 1023) offsets[total] = psum[1023];
+  u32* dst = offsets + (size_t)w * NBUCKET + t * PER;
+#pragma unroll
+  for (int j = 0; j < PER; j++) { dst[j] = run; run += src[j]; }
+  if (t == 1023) win_total[w] = psum[1023];
+}
+__global__ void __launch_bounds__(256) scan_base_kernel(u32* offsets, const u32* win_total) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > NWIN * NBUCKET) return;
+  const int w = (j == NWIN * NBUCKET) ? NWIN : j / NBUCKET;
+  u32 base = 0;
+#pragma unroll 1
+  for (int v = 0; v < w; v++) base += win_total[v];
+  if (j == NWIN * NBUCKET) offsets[j] = base;          // one past the end: the number of sorted entries
+  else offsets[j] += base;
 }
 // 2c. part[w][g][b] becomes the first output slot of chunk g inside bucket (w, b)
 __global__ void __launch_bounds__(256) cursors_kernel(u32* part, const u32* offsets) {
@@ -261,9 +275,9 @@ __global__ void __launch_bounds__(64) sum_kernel(const JacK256* in, JacK256* out
 //      S_w = sumW0 + SEG0 * ( sum_{s1} (Wt1 - T1)  +  SEG1 * sum_{s1} s1 * T1 )
 //    One workgroup per window, lane s1 owns one level-1 segment (and one of the NSUMW partial sums of the level-0
 //    weighted parts); the three sums over the lanes are LDS tree reductions, so the dependent chain is
-//    log2(32) additions instead of 32 x 4.
+//    log2(NSEG1) additions instead of NSEG1 x 4.
 __global__ void __launch_bounds__(NSEG1) window_kernel(const JacK256* t1, const JacK256* w1, const JacK256* sumw0, JacK256* win) {
-  static_assert(NSEG1 == 32 && NSUMW == 32, "one lane per level-1 segment and per partial sum");
+  static_assert(NSUMW == NSEG1 && NSEG1 <= 1024, "one lane per level-1 segment and per partial sum");
   __shared__ JacK256 sh[NSEG1];
   const int w = blockIdx.x, s = threadIdx.x;          // blockDim.x == NSEG1
   JacK256 inner, acc, sw;
@@ -272,9 +286,9 @@ __global__ void __launch_bounds__(NSEG1) window_kernel(const JacK256* t1, const 
   JacK256 neg = T;
   k256::neg(neg.y, neg.y);
   jac_add(inner, w1[w * NSEG1 + s], neg);            // Wt1 - T1
-  // s * T by double-and-add over the 5 bits of s
+  // s * T by double-and-add over the bits of s
 #pragma unroll 1
-  for (int bit = LOG_SEG1 - 1; bit >= 0; bit--) {
+  for (int bit = LOG_NSEG1 - 1; bit >= 0; bit--) {
     k256::jac_double(acc);
     if ((s >> bit) & 1) jac_add(acc, acc, T);
   }

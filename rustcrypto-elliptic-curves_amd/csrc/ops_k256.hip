@@ -40,7 +40,7 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   const size_t nb = (size_t)NWIN * NBUCKET;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t sz_aff = (pt_fmt == FMT_PROJECTIVE) ? al(n * 64) : 0;
-  const size_t sz_hist = al((nb + 1) * 4), sz_sorted = al((size_t)NWIN * n * 4 + 4);
+  const size_t sz_hist = al((nb + 1 + NWIN) * 4), sz_sorted = al((size_t)NWIN * n * 4 + 4);
   const size_t sz_part = al((size_t)NWIN * SORT_CHUNKS * NBUCKET * 4);
   const size_t sz_buckets = al(nb * sizeof(JacK256));
   const size_t n0 = (size_t)NWIN * NSEG0, n1 = (size_t)NWIN * NSEG1, nsw = (size_t)NWIN * NSUMW;
@@ -82,7 +82,9 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   const unsigned sort_grid = NWIN * SORT_CHUNKS, nb_grid = (unsigned)((nb + 255) / 256);
   hipLaunchKernelGGL(hist_kernel, dim3(sort_grid), dim3(1024), 0, c->stream, sc, n, part);
   hipLaunchKernelGGL(totals_kernel, dim3(nb_grid), dim3(256), 0, c->stream, (const u32*)part, hist);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u32*)hist, offsets, (int)nb);
+  u32* win_total = hist + nb + 1;    // per-window totals live behind the bucket totals
+  hipLaunchKernelGGL(scan_kernel, dim3(NWIN), dim3(1024), 0, c->stream, (const u32*)hist, offsets, win_total);
+  hipLaunchKernelGGL(scan_base_kernel, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, c->stream, offsets, (const u32*)win_total);
   hipLaunchKernelGGL(cursors_kernel, dim3(nb_grid), dim3(256), 0, c->stream, part, (const u32*)offsets);
   hipLaunchKernelGGL(scatter_kernel, dim3(sort_grid), dim3(1024), 0, c->stream, sc, n, (const u32*)part, sorted);
   HIPCHK(c, hipMemsetAsync(heavy_ctr, 0, 8, c->stream));
