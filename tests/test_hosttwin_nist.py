@@ -36,6 +36,8 @@ def test_field_ops(cn, cid, ref_vectors):
     xm = [(a * rinv) % p for a in edge + hi for _ in edge + hi]
     ym = [(b * rinv) % p for _ in edge + hi for b in edge + hi]
     assert fe_run(cid, c, 0, xm, ym) == [x * y % p for x, y in zip(xm, ym)]
+    xs2 = sorted(set(xm)) + [rng.randrange(p) for _ in range(1500)]
+    assert fe_run(cid, c, 1, xs2) == [x * x % p for x in xs2]          # p384 squares on its own path
     assert fe_run(cid, c, 2, xs, ys) == [(x + y) % p for x, y in zip(xs, ys)]
     assert fe_run(cid, c, 3, xs, ys) == [(x - y) % p for x, y in zip(xs, ys)]
     assert fe_run(cid, c, 1, xs) == [x * x % p for x in xs]
