@@ -80,6 +80,9 @@ WORKLOADS = {
 # v_mad_u64_u32 issues at half the FP32-FMA rate on gfx950 (measured, tools/ubench/valu_rates.hip):
 # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz
 PEAK_TMACS = 256 * 4 * 16 * 2.4e9 / 1e12
+# one exact multiply-accumulate is the pair v_mad_u64_u32 + v_addc_co_u32: 9.54 cycles per wave per SIMD at the
+# kernels' occupancy (profiles/r01_mac_mix_microbench.txt) -> the ceiling any column-accumulating schedule can reach
+MAC_PAIR_PEAK_TMACS = 256 * 4 * 64 * 2.4e9 / 9.54 / 1e12
 PEAK_HBM_GBS = 8000.0
 
 
@@ -345,6 +348,7 @@ def main():
                 "frac": achieved_tmacs / PEAK_TMACS, "traffic": traffic,
                 "kernel": wl["kernel"] or ("lincomb_ref_kernel<CurveK256,1>" if args.schedule == "ref" else "k256_mul_fast_kernel<16,4>"), "kernel_ms": kernel_s * 1e3,
                 "modmul_per_unit": modmul, "mac_per_unit": modmul * wl["mac"],
+                "mac_pair_peak": MAC_PAIR_PEAK_TMACS, "frac_of_mac_pair_peak": achieved_tmacs / MAC_PAIR_PEAK_TMACS,
                 "hbm": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": alg_bytes / kernel_s / 1e9 / PEAK_HBM_GBS, "bytes_per_unit": BYTES_PER_UNIT},
             },

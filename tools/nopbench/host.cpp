@@ -9,7 +9,8 @@ int main(int argc, char** argv) {
   hipModule_t m; hipFunction_t f;
   CK(hipModuleLoad(&m, argv[1]));
   CK(hipModuleGetFunction(&f, m, "kloop"));
-  const int blocks = 256 * 4, threads = 256;
+  const int per_cu = argc > 3 ? atoi(argv[3]) : 4;      // workgroups of 4 waves per CU = waves per SIMD
+  const int blocks = 256 * per_cu, threads = 256;
   size_t n = (size_t)blocks * threads;
   std::vector<unsigned> h(n * 8);
   for (size_t i = 0; i < n * 8; i++) h[i] = 0x9E3779B9u * (unsigned)(i + 1) + 12345u;
@@ -25,7 +26,7 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned> out(16);
     CK(hipMemcpy(out.data(), o, 64, hipMemcpyDeviceToHost));
-    printf("%s iters=%d  %.3f ms  %.2f G modmul/s  chk=%08x%08x\n", argv[1], iters, ms, 3.0 * iters * n / ms / 1e6, out[0], out[9]);
+    printf("%s waves/SIMD=%d iters=%d  %.3f ms  %.2f G modmul/s  chk=%08x%08x\n", argv[1], per_cu, iters, ms, 3.0 * iters * n / ms / 1e6, out[0], out[9]);
   }
   return 0;
 }
