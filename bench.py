@@ -126,18 +126,38 @@ def cpu_baseline_worker(args):
     return first, n, dt, out.tobytes()
 
 
-def run_cpu_baseline(sample, procs, cid=0, fixed=False, msm=False):
-    """Reference CPU path (C port) on `sample` units spread over `procs` single-threaded processes."""
+SPREAD_BLOCKS, SPREAD_LEN = 16, 4096     # extra parity blocks spread over the batch (sampled indices + the tail)
+
+
+def spread_blocks(n, sample):
+    """Start indices of the extra checked blocks: evenly spaced behind the timed sample, the last one ending the batch."""
+    if n <= sample + SPREAD_BLOCKS * SPREAD_LEN:
+        return []
+    span = n - sample - SPREAD_LEN
+    return [sample + (span * j) // (SPREAD_BLOCKS - 1) for j in range(SPREAD_BLOCKS)]
+
+
+def run_cpu_baseline(sample, procs, cid=0, fixed=False, msm=False, n=0):
+    """Reference CPU path (C port) on `sample` units spread over `procs` single-threaded processes; for the
+    element-wise workloads also SPREAD_BLOCKS blocks of SPREAD_LEN units across the rest of the batch (checked, not
+    part of the timed sample)."""
     from concurrent.futures import ProcessPoolExecutor
     per = (sample + procs - 1) // procs
     jobs = [(i * per, min(per, sample - i * per), cid, fixed, msm) for i in range(procs) if i * per < sample]
+    extra = [] if msm else [(st, SPREAD_LEN, cid, fixed, msm) for st in spread_blocks(n, sample)]
+    if extra:
+        with ProcessPoolExecutor(max_workers=procs) as ex:
+            extra_res = [(r[0], r[1], r[3]) for r in ex.map(cpu_baseline_worker, extra)]
+    else:
+        extra_res = []
     t0 = time.perf_counter()
     with ProcessPoolExecutor(max_workers=procs) as ex:
         res = list(ex.map(cpu_baseline_worker, jobs))
     wall = time.perf_counter() - t0
     busy = max(r[2] for r in res)      # slowest worker, excludes process start-up and input synthesis
     outs = b"".join(r[3] for r in sorted(res))
-    return {"wall_s": wall, "busy_s": busy, "out": outs, "procs": len(jobs), "parts": [(r[0], r[1], r[3]) for r in sorted(res)]}
+    return {"wall_s": wall, "busy_s": busy, "out": outs, "procs": len(jobs), "parts": [(r[0], r[1], r[3]) for r in sorted(res)],
+            "extra": extra_res}
 
 
 def main():
@@ -174,7 +194,7 @@ def main():
         if wl.get("ecdsa"):
             per_proc //= 2                  # a verification is two scalar multiplications on the CPU
             sample = args.cpu_sample or min(n, per_proc * procs)
-        cpu = run_cpu_baseline(sample, procs, wl["cid"], wl["fixed"], "ecdsa" if wl.get("ecdsa") else wl["msm"])
+        cpu = run_cpu_baseline(sample, procs, wl["cid"], wl["fixed"], "ecdsa" if wl.get("ecdsa") else wl["msm"], n)
         cpu["sample"] = sample
 
     import numpy as np
@@ -305,6 +325,8 @@ def main():
         else:
             got = torch.cat([d_o[:m], d_i[:m, None]], dim=1).cpu().numpy().tobytes()
             parity = (got == cpu["out"])
+            for lo, cnt, blob in cpu["extra"]:       # blocks spread over the rest of the batch, the last one at its end
+                parity &= (torch.cat([d_o[lo:lo + cnt], d_i[lo:lo + cnt, None]], dim=1).cpu().numpy().tobytes() == blob)
         if not parity:
             raise SystemExit("PARITY FAILURE: GPU output differs from the CPU oracle on the sampled units")
 
@@ -356,7 +378,8 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = {
                 "value": cpu["sample"] / cpu["busy_s"], "unit": wl["unit"], "cores": cpu["procs"], "kind": "port",
-                "sample": "first %d units of the same seeded batch, C restatement of the reference path (oracle/ecoracle.c), %d single-threaded processes; GPU output of the sample verified byte-identical" % (cpu["sample"], cpu["procs"]),
+                "sample": "first %d units of the same seeded batch, C restatement of the reference path (oracle/ecoracle.c), %d single-threaded processes; GPU output of the sample%s verified byte-identical" % (
+                    cpu["sample"], cpu["procs"], (" and of %d more blocks of %d units spread to the end of the batch" % (len(cpu["extra"]), SPREAD_LEN)) if cpu.get("extra") else ""),
                 "wall_s": cpu["wall_s"], "parity_ok": bool(parity),
             }
         print(json.dumps(line), flush=True)
