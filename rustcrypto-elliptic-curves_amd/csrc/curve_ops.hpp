@@ -53,15 +53,19 @@ struct CurveOps {
   static int ensure_fb_table(ecgpu_ctx* c) {
     if (c->fb_table[C::ID]) return 0;
     const int total = fb::nwin<C>() * fb::ENTRIES;
-    void *tmp = nullptr, *tab = nullptr;
-    HIPCHK(c, hipMalloc(&tmp, sizeof(Jac<C>) * total));
-    HIPCHK(c, hipMalloc(&tab, sizeof(AffEntry<C>) * total));
+    struct Tmp {                       // released on every exit path
+      void* p = nullptr;
+      ~Tmp() { if (p) (void)hipFree(p); }
+    } ttmp, ttab;
+    HIPCHK(c, hipMalloc(&ttmp.p, sizeof(Jac<C>) * total));
+    HIPCHK(c, hipMalloc(&ttab.p, sizeof(AffEntry<C>) * total));
+    void *tmp = ttmp.p, *tab = ttab.p;
     hipLaunchKernelGGL((fb::table_jac_kernel<C>), dim3((fb::nwin<C>() + 63) / 64), dim3(64), 0, c->stream, (Jac<C>*)tmp);
     hipLaunchKernelGGL((fb::table_affine_kernel<C>), dim3((total + 255) / 256), dim3(256), 0, c->stream, (const Jac<C>*)tmp, (AffEntry<C>*)tab, total);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(tmp));
     c->fb_table[C::ID] = tab;
+    ttab.p = nullptr;                  // owned by the context from here on
     return 0;
   }
   // wide tables TW[j][d-1] = d 2^(WB j) G, 2^(WB-1) entries per window, built by multiplying the scalars d 2^(WB j)
@@ -73,10 +77,14 @@ struct CurveOps {
     int rc = ensure_fb_table(c);
     if (rc) return rc;
     const size_t total = (size_t)fb::nwin_wide<C, WB>() * fb::wide_entries<WB>();
-    void *ks = nullptr, *xy = nullptr, *tab = nullptr;
-    HIPCHK(c, hipMalloc(&ks, total * C::NB));
-    HIPCHK(c, hipMalloc(&xy, total * 2 * C::NB));
-    HIPCHK(c, hipMalloc(&tab, total * sizeof(AffEntry<C>)));
+    struct Tmp {                       // released on every exit path
+      void* p = nullptr;
+      ~Tmp() { if (p) (void)hipFree(p); }
+    } tks, txy, ttab;
+    HIPCHK(c, hipMalloc(&tks.p, total * C::NB));
+    HIPCHK(c, hipMalloc(&txy.p, total * 2 * C::NB));
+    HIPCHK(c, hipMalloc(&ttab.p, total * sizeof(AffEntry<C>)));
+    void *ks = tks.p, *xy = txy.p, *tab = ttab.p;
     hipLaunchKernelGGL((fb::table_scalars_kernel<C, WB>), dim3(ecgpu_grid_for(c, total, 8)), dim3(256), 0, c->stream, (u32*)ks, total);
     hipLaunchKernelGGL((fb::mul_kernel<C, 16, 4>), dim3(ecgpu_grid_for(c, total, 4)), dim3(256), 0, c->stream, (const u32*)ks,
                        (const AffEntry<C>*)c->fb_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, total);
@@ -84,9 +92,8 @@ struct CurveOps {
                        (AffEntry<C>*)tab, total);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(ks));
-    HIPCHK(c, hipFree(xy));
     *slot = tab;
+    ttab.p = nullptr;                  // the context owns the table now; the two scratch buffers go with this scope
     return 0;
   }
   static int mul_gen_fast(ecgpu_ctx* c, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {

@@ -115,9 +115,12 @@ def _ptr(x):
     if isinstance(x, int):
         return ctypes.c_void_p(x), None
     if isinstance(x, np.ndarray):
-        assert x.flags["C_CONTIGUOUS"]
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ValueError("the C ABI takes dense buffers: pass a C-contiguous array")
         return ctypes.c_void_p(x.ctypes.data), x
     if hasattr(x, "data_ptr"):  # torch tensor
+        if not x.is_contiguous():
+            raise ValueError("the C ABI takes dense buffers: pass a contiguous tensor")
         return ctypes.c_void_p(x.data_ptr()), x
     raise TypeError(type(x))
 
