@@ -238,6 +238,18 @@ template <class M> ECGPU_HD void set_one(FeMont<M>& r) {
 }
 template <class M> ECGPU_HD void neg(FeMont<M>& r, const FeMont<M>& a) { FeMont<M> z; set_zero(z); sub(r, z, a); }
 template <class M> ECGPU_HD void dbl(FeMont<M>& r, const FeMont<M>& a) { add(r, a, a); }
+// r = a / 2: (a + p) >> 1 for odd a (halving acts on the represented element whatever the Montgomery factor)
+template <class M>
+ECGPU_HD void half(FeMont<M>& r, const FeMont<M>& a) {
+  constexpr int N = M::N;
+  const bool odd = (a.v[0] & 1u) != 0;
+  u32 t[N], c = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = addc(a.v[i], odd ? M::P[i] : 0u, c);
+#pragma unroll
+  for (int i = 0; i < N - 1; i++) r.v[i] = (t[i] >> 1) | (t[i + 1] << 31);
+  r.v[N - 1] = (t[N - 1] >> 1) | (c << 31);
+}
 template <class M> ECGPU_HD bool is_zero(const FeMont<M>& a) { return mp_is_zero<M::N>(a.v); }
 template <class M> ECGPU_HD bool equal(const FeMont<M>& a, const FeMont<M>& b) { return mp_eq<M::N>(a.v, b.v); }
 template <class M> ECGPU_HD void select(FeMont<M>& r, bool c, const FeMont<M>& a, const FeMont<M>& b) { mp_select<M::N>(r.v, c, a.v, b.v); }

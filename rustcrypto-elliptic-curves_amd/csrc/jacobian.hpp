@@ -22,7 +22,7 @@ namespace jac {
 template <class C> ECGPU_HD void set_infinity(Jac<C>& p) { C::fe_zero(p.x); C::fe_zero(p.y); C::fe_zero(p.z); }
 template <class C> ECGPU_HD void fe_dbl(typename C::Fe& r, const typename C::Fe& a) { C::fe_add(r, a, a); }
 
-// In-place doubling.  a = 0 (k256): 3M + 4S.  a = -3 (NIST): 3M + 5S (dbl-2001-b).
+// In-place doubling.  a = 0 (k256): 3M + 4S.  a = -3 (NIST): 4M + 4S (dbl-2004-hmv).
 template <class C>
 ECGPU_HD void dbl(Jac<C>& p) {
   using Fe = typename C::Fe;
@@ -40,20 +40,28 @@ ECGPU_HD void dbl(Jac<C>& p) {
     fe_dbl<C>(b, b); fe_dbl<C>(b, b); fe_dbl<C>(b, b);
     C::fe_sub(p.y, p.y, b);
   } else {
-    // delta = Z^2, gamma = Y^2, beta = X gamma, alpha = 3 (X - delta)(X + delta),
-    // X3 = alpha^2 - 8 beta, Z3 = (Y + Z)^2 - gamma - delta, Y3 = alpha (4 beta - X3) - 8 gamma^2
-    Fe delta, gamma, beta, alpha, t;
-    C::fe_sqr(delta, p.z);
-    C::fe_sqr(gamma, p.y);
-    C::fe_mul(beta, p.x, gamma);
-    C::fe_sub(t, p.x, delta); C::fe_add(alpha, p.x, delta); C::fe_mul(alpha, t, alpha);
-    fe_dbl<C>(t, alpha); C::fe_add(alpha, t, alpha);
-    C::fe_add(t, p.y, p.z); C::fe_sqr(t, t); C::fe_sub(t, t, gamma); C::fe_sub(p.z, t, delta);
-    fe_dbl<C>(beta, beta); fe_dbl<C>(beta, beta);                           // 4 beta
-    C::fe_sqr(t, alpha); C::fe_sub(t, t, beta); C::fe_sub(p.x, t, beta);    // X3
-    C::fe_sub(t, beta, p.x); C::fe_mul(t, alpha, t);
-    C::fe_sqr(gamma, gamma); fe_dbl<C>(gamma, gamma); fe_dbl<C>(gamma, gamma); fe_dbl<C>(gamma, gamma);
-    C::fe_sub(p.y, t, gamma);
+    // dbl-2004-hmv, 4M + 4S with one halving: the additions of a fully reduced Montgomery field cost ~10 % of a
+    // multiplication each, and this form needs 10 of them where dbl-2001-b (3M + 5S) needs 17.
+    //   alpha = 3 (X - Z^2)(X + Z^2), Z3 = 2 Y Z, beta4 = 4 X Y^2, X3 = alpha^2 - 2 beta4,
+    //   Y3 = alpha (beta4 - X3) - 8 Y^4   with 8 Y^4 = (2Y)^4 / 2
+    Fe t1, t2, t3;
+    C::fe_sqr(t1, p.z);
+    C::fe_sub(t2, p.x, t1);
+    C::fe_add(t1, p.x, t1);
+    C::fe_mul(t2, t1, t2);
+    fe_dbl<C>(t1, t2); C::fe_add(t2, t1, t2);            // alpha
+    fe_dbl<C>(p.y, p.y);                                 // 2Y
+    C::fe_mul(p.z, p.y, p.z);                            // Z3
+    C::fe_sqr(p.y, p.y);                                 // 4 Y^2
+    C::fe_mul(t3, p.y, p.x);                             // beta4
+    C::fe_sqr(p.y, p.y);                                 // 16 Y^4
+    C::fe_half(p.y, p.y);                                // 8 Y^4
+    C::fe_sqr(p.x, t2);
+    fe_dbl<C>(t1, t3);
+    C::fe_sub(p.x, p.x, t1);                             // X3
+    C::fe_sub(t1, t3, p.x);
+    C::fe_mul(t1, t1, t2);
+    C::fe_sub(p.y, t1, p.y);                             // Y3
   }
 }
 

@@ -94,6 +94,7 @@ struct CurveNist {
   static ECGPU_HD void fe_add(Fe& r, const Fe& a, const Fe& b) { mont::add(r, a, b); }
   static ECGPU_HD void fe_sub(Fe& r, const Fe& a, const Fe& b) { mont::sub(r, a, b); }
   static ECGPU_HD void fe_neg(Fe& r, const Fe& a) { mont::neg(r, a); }
+  static ECGPU_HD void fe_half(Fe& r, const Fe& a) { mont::half(r, a); }
   static ECGPU_HD void fe_inv(Fe& r, const Fe& a) { mont::inv(r, a); }
   static ECGPU_HD bool fe_sqrt(Fe& r, const Fe& a) { return mont::sqrt(r, a); }
   static ECGPU_HD bool fe_is_zero(const Fe& a) { return mont::is_zero(a); }
