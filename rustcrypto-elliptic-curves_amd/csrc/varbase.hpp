@@ -2,7 +2,7 @@
 // endomorphism (P-256, P-384).  The reference computes this with complete homogeneous formulas, an
 // unsigned 4-bit window and a 16-entry table (primeorder/src/projective.rs:106-150: 4361 / 6473
 // field multiplications); the group element is what is specified, so here:
-//   * Jacobian coordinates (doubling 3M+5S for a = -3, general addition 11M+5S);
+//   * Jacobian coordinates (doubling 4M+4S with a halving for a = -3, general addition 11M+5S);
 //   * signed 4-bit digits (k > n/2 is replaced by n - k and -P): table [P .. 8P] of 8 Jacobian points
 //     per lane in a lane-contiguous global workspace, built with 4 doublings and 3 mixed additions;
 //   * per-lane batched conversion to affine (one inversion per BATCH results).
