@@ -1,6 +1,9 @@
 // NIST P256 kernels and launchers (one translation unit per curve: the library builds in parallel).
 #include "curve_ops.hpp"
 #include "varbase.hpp"
+#ifndef VBB
+#define VBB 8          // units per lane and pass of the variable-base kernel (tables share one inversion)
+#endif
 using namespace ecgpu;
 
 template <>
@@ -10,17 +13,18 @@ int CurveOps<CurveP256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
     // ECGPU_VB_WAVES (2/3/4) picks the occupancy variant; the default is the measured best
     static const int waves = [] { const char* e = getenv("ECGPU_VB_WAVES"); int w = e ? atoi(e) : 4; return (w < 2 || w > 4) ? 4 : w; }();
     const dim3 grid(ecgpu_grid_for(c, n, waves));
-    // per-lane table workspace (8 Jacobian points per resident lane), grow-only, shared with the other curves' kernels
-    const size_t ws_need = (size_t)grid.x * 256 * 8 * sizeof(Jac<CurveP256>);
+    // per-lane workspace (8 tables of 8 points and the prefix products of their shared inversion per resident lane),
+    // grow-only, shared with the other curves' kernels
+    const size_t ws_need = (size_t)grid.x * 256 * sizeof(vb::LaneWs<CurveP256, VBB>);
     if (ws_need > c->tab_ws_cap) {
       if (c->tab_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->tab_ws)); c->tab_ws = nullptr; c->tab_ws_cap = 0; }
       HIPCHK(c, hipMalloc(&c->tab_ws, ws_need));
       c->tab_ws_cap = ws_need;
     }
-    Jac<CurveP256>* ws = (Jac<CurveP256>*)c->tab_ws;
-    if (waves == 2) hipLaunchKernelGGL((vb::mul_kernel<CurveP256, 8, 2>), grid, dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
-    else if (waves == 3) hipLaunchKernelGGL((vb::mul_kernel<CurveP256, 8, 3>), grid, dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
-    else hipLaunchKernelGGL((vb::mul_kernel<CurveP256, 8, 4>), grid, dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
+    vb::LaneWs<CurveP256, VBB>* ws = (vb::LaneWs<CurveP256, VBB>*)c->tab_ws;
+    if (waves == 2) hipLaunchKernelGGL((vb::mul_kernel<CurveP256, VBB, 2>), grid, dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
+    else if (waves == 3) hipLaunchKernelGGL((vb::mul_kernel<CurveP256, VBB, 3>), grid, dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
+    else hipLaunchKernelGGL((vb::mul_kernel<CurveP256, VBB, 4>), grid, dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
     HIPCHK(c, hipGetLastError());
     return 1;
   }
