@@ -60,8 +60,9 @@ WORKLOADS = {
                            modmul=13 * 11 + 7 + 24, mac=64, bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,20,16,4>",
                            desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
     "p384_varbase":   dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
-                           # 96 windows x (4 doublings (4M+4S) + 15/16 general additions (11M+5S)) + table (4 dbl + 3 add) + normalise
-                           modmul=96 * (32 + 15) + 80 + 7 + 72, mac=144, bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,4>",
+                           # 96 windows x (4 doublings (4M+4S) + 15/16 mixed additions (8M+3S)) + table (4 dbl + 3 add = 80) + its share of the
+                           # affine conversion (8 x 7 + 430 / 8) + output normalise 7 + 430 / 8
+                           modmul=96 * 32 + 90 * 11 + 80 + 110 + 61, mac=144, bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,4>",
                            desc="p384 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
     "k256_msm":       dict(curve="k256", cid=0, log2n=23, fixed=False, msm=True, metric="k256 MSM points/sec", unit="points/s",
                            # 16 signed 16-bit windows: one mixed addition (8M+3S) per term per window; bucket reduction amortised
