@@ -133,3 +133,44 @@ def test_host_buffer_pipeline_matches_device_path(env):
     s2, r2, k2 = CO.ecdsa_sign_batch(0, hs[idx], hk[idx], hz[idx], low_s=True)
     good = idx % 4099 != 0
     assert bytes(sig[idx][good]) == bytes(s2[good]) and bytes(rec[idx]) == bytes(r2)
+
+
+@pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1), ("p384", 2)])
+def test_ragged_batch_sizes_are_prefix_consistent(cn, cid):
+    """Element i of a batch must not depend on the batch size: every kernel walks its batch with grid strides and
+    per-lane sub-batches (shared inversions), so sizes around the wave, workgroup and grid boundaries are compared
+    with the prefix of one large batch (whose head is checked against the C oracle)."""
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cn)
+    nb = cv.nb
+    big = 70001
+    s = CO.synth_scalars(cid, big, synth.SEED, 31)
+    p = CO.synth_points(cid, big, synth.SEED, 31)
+    s[3] = 0                                        # identity result
+    p[9] = 0                                        # identity input
+    out, inf = cv.mul(s, p)
+    gen, ginf = cv.mul_by_generator(s)
+    want = CO.lincomb_batch(cid, s[:300], p[:300], threads=4)
+    assert bytes(np.concatenate([out[:300], inf[:300, None]], axis=1)) == bytes(want)
+    z = CO.synth_scalars(cid, big, synth.SEED + 2, 31)
+    k = CO.synth_scalars(cid, big, synth.SEED + 1, 31)
+    d = s.copy()
+    d[3, -1] = 5
+    sig, rec, okd = cv.ecdsa_sign(d, k, z)
+    keys, _ = cv.mul_by_generator(d)
+    sig[::7, 5] ^= 1
+    ver = cv.ecdsa_verify(z, sig, keys)
+    enc = cv.to_bytes(out)
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 1023, 1025, 4095, 4097, 16385, 65537):
+        o2, i2 = cv.mul(s[:n], p[:n])
+        assert bytes(o2) == bytes(out[:n]) and bytes(i2) == bytes(inf[:n]), n
+        g2, gi2 = cv.mul_by_generator(s[:n])
+        assert bytes(g2) == bytes(gen[:n]) and bytes(gi2) == bytes(ginf[:n]), n
+        assert bytes(cv.ecdsa_verify(z[:n], sig[:n], keys[:n])) == bytes(ver[:n]), n
+        s2, r2, k2 = cv.ecdsa_sign(d[:n], k[:n], z[:n])
+        s2[::7, 5] ^= 1
+        assert bytes(s2) == bytes(sig[:n]) and bytes(r2) == bytes(rec[:n]), n
+        assert bytes(cv.to_bytes(out[:n])) == bytes(enc[:n]), n
+    assert ver.sum() == big - len(range(0, big, 7))
+    ctx.close()
