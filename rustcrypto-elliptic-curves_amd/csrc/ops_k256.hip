@@ -39,6 +39,32 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   if (n >= (size_t)1 << 31) return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_msm: at most 2^31 - 1 terms per call");
   const size_t nb = (size_t)NWIN * NBUCKET;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  // ECGPU_MSM_SMALL = 0 forces the bucket method for every size (measurements, tests of the bucket path on small inputs)
+  // (read per call so that one process can exercise both paths)
+  const char* small_env = getenv("ECGPU_MSM_SMALL");
+  const bool small_path = !(small_env && atoi(small_env) == 0);
+  if (small_path && n > 0 && n < SMALL_MSM_TERMS) {
+    // n scalar multiplications on the throughput kernel, then a two-level sum of the products
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    const size_t sz_prod = al(n * 64), sz_part = al((size_t)blocks * sizeof(JacK256)), sz_win = al(sizeof(JacK256));
+    const size_t need = sz_prod + sz_part + sz_win;
+    if (need > c->msm_ws_cap) {
+      if (c->msm_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->msm_ws)); c->msm_ws = nullptr; c->msm_ws_cap = 0; }
+      HIPCHK(c, hipMalloc(&c->msm_ws, need));
+      c->msm_ws_cap = need;
+    }
+    char* p = (char*)c->msm_ws;
+    u32* prod = (u32*)p; p += sz_prod;
+    JacK256* partial = (JacK256*)p; p += sz_part;
+    JacK256* win = (JacK256*)p;
+    int rc = lincomb(c, sc, pts, pt_fmt, 1, prod, FMT_AFFINE, nullptr, n, 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_affine_kernel, dim3(blocks), dim3(256), 0, c->stream, (const u32*)prod, n, partial);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, (const JacK256*)partial, blocks, win);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, c->stream, (const JacK256*)win, 1, out, out_fmt);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   const size_t sz_aff = (pt_fmt == FMT_PROJECTIVE) ? al(n * 64) : 0;
   const size_t sz_hist = al((nb + 1 + NWIN) * 4), sz_sorted = al((size_t)NWIN * n * 4 + 4);
   const size_t sz_part = al((size_t)NWIN * SORT_CHUNKS * NBUCKET * 4);
@@ -98,7 +124,7 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   hipLaunchKernelGGL(segment_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, c->stream, t0, t1, w1, SEG1, (int)n1);
   hipLaunchKernelGGL(sum_kernel, dim3((unsigned)((nsw + 63) / 64)), dim3(64), 0, c->stream, w0, sumw0, SUMW_LEN, (int)nsw);
   hipLaunchKernelGGL(window_kernel, dim3(NWIN), dim3(NSEG1), 0, c->stream, t1, w1, sumw0, win);
-  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, c->stream, win, out, out_fmt);
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, c->stream, (const JacK256*)win, (int)NWIN, out, out_fmt);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

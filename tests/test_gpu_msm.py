@@ -13,12 +13,20 @@ C = M.K256
 N = C.n
 
 
-@pytest.fixture(scope="module")
-def curve():
+@pytest.fixture(scope="module", params=["auto", "buckets"])
+def curve(request):
+    """Every test runs twice: with the library's own choice (below 2^19 terms: n scalar multiplications and a tree
+    sum) and with the bucket method forced for all sizes (ECGPU_MSM_SMALL=0, read per call)."""
+    import os
     import ecgpu
+    if request.param == "buckets":
+        os.environ["ECGPU_MSM_SMALL"] = "0"
+    else:
+        os.environ.pop("ECGPU_MSM_SMALL", None)
     ctx = ecgpu.Context(0)
     yield ctx.curve("k256")
     ctx.close()
+    os.environ.pop("ECGPU_MSM_SMALL", None)
 
 
 def arr(rows, w):
