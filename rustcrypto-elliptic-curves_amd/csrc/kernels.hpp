@@ -161,8 +161,11 @@ __global__ void __launch_bounds__(256) normalize_kernel(const u32* p, u32* out_x
 }
 
 // Reference-faithful n independent linear combinations of NT terms (NT = 1 is `&P * &k`).
+#ifndef ECGPU_REF_WAVES
+#define ECGPU_REF_WAVES 2          // occupancy target of the reference-schedule kernels (measured: see DESIGN.md section 4)
+#endif
 template <class C, int NT>
-__global__ void __launch_bounds__(256) lincomb_ref_kernel(const u32* scalars, const u32* points, int pt_fmt,
+__global__ void __launch_bounds__(256, ECGPU_REF_WAVES) lincomb_ref_kernel(const u32* scalars, const u32* points, int pt_fmt,
                                                           u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
   typename C::Pt tab[C::REF_TABLE_PTS * NT];
   ECGPU_GRID_STRIDE(i, n) {
