@@ -128,7 +128,7 @@ struct Acc96 {
 // c += a * b
 ECGPU_HD void mac(Acc96& c, u32 a, u32 b) {
 #if ECGPU_ASM
-  asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
       : "+v"(c.lo), "+v"(c.hi)
       : "v"(a), "v"(b)
       : "vcc");
