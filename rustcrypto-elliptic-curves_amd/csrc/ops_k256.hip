@@ -2,6 +2,9 @@
 #include "curve_ops.hpp"
 #include "msm_kernels.hpp"
 using namespace ecgpu;
+#ifndef MSM_BUCKET_WGS_PER_CU
+#define MSM_BUCKET_WGS_PER_CU 8      // bucket-sum workgroups per CU: lanes then take two or three buckets each (measured 4 / 8 / 16: 16.7 / 16.0 / 16.2 ms)
+#endif
 
 template <>
 int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt,
@@ -114,7 +117,7 @@ int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt
   hipLaunchKernelGGL(cursors_kernel, dim3(nb_grid), dim3(256), 0, c->stream, part, (const u32*)offsets);
   hipLaunchKernelGGL(scatter_kernel, dim3(sort_grid), dim3(1024), 0, c->stream, sc, n, (const u32*)part, sorted);
   HIPCHK(c, hipMemsetAsync(heavy_ctr, 0, 8, c->stream));
-  hipLaunchKernelGGL(bucket_sum_kernel, dim3(ecgpu_grid_for(c, nb, 16)), dim3(256), 0, c->stream, xy, offsets, sorted, buckets, (int)nb, cap, heavy_ctr,
+  hipLaunchKernelGGL(bucket_sum_kernel, dim3(ecgpu_grid_for(c, nb, MSM_BUCKET_WGS_PER_CU)), dim3(256), 0, c->stream, xy, offsets, sorted, buckets, (int)nb, cap, heavy_ctr,
                      heavy, chunks);
   hipLaunchKernelGGL(heavy_chunk_kernel, dim3((unsigned)c->num_cus * 8), dim3(256), 0, c->stream, xy, (const u32*)offsets, (const u32*)sorted, cap,
                      (const u32*)heavy_ctr, (const HeavyChunk*)chunks, partial);
