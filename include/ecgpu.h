@@ -189,7 +189,10 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* prehash, 
                              const uint8_t* pubkeys_xy, uint8_t* ok, size_t n, int mem, unsigned flags);
 /* sig_rs[i] = (r, s) with R = k G, r = x(R) mod n, s = k^-1 (z + r d) mod n; recovery_id[i] (optional) =
  * y_is_odd(R) | x_is_reduced << 1; ok[i] = 0 (and a zero signature) when d or k is outside [1, n-1]
- * or r = 0 or s = 0, where the reference returns Err. */
+ * or r = 0 or s = 0, where the reference returns Err.
+ * Note: k G runs on the throughput fixed-base schedule (table lookups and branches indexed by digits of k); unlike the
+ * reference's mul_by_generator it is not constant-time.  The values are identical; whether that matters depends on
+ * who shares the device. */
 int ecgpu_ecdsa_sign_batch(ecgpu_ctx* ctx, int curve, const uint8_t* secret_d, const uint8_t* nonce_k,
                            const uint8_t* prehash, uint8_t* sig_rs, uint8_t* recovery_id, uint8_t* ok,
                            size_t n, int mem, unsigned flags);
