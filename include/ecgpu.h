@@ -192,7 +192,7 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* prehash, 
  * or r = 0 or s = 0, where the reference returns Err.
  * Note: k G runs on the throughput fixed-base schedule (table lookups and branches indexed by digits of k); unlike the
  * reference's mul_by_generator it is not constant-time.  The values are identical; whether that matters depends on
- * who shares the device. */
+ * who shares the device; ECGPU_EXACT_REFERENCE in `flags` selects the reference's schedule for k G instead. */
 int ecgpu_ecdsa_sign_batch(ecgpu_ctx* ctx, int curve, const uint8_t* secret_d, const uint8_t* nonce_k,
                            const uint8_t* prehash, uint8_t* sig_rs, uint8_t* recovery_id, uint8_t* ok,
                            size_t n, int mem, unsigned flags);

@@ -291,7 +291,8 @@ struct CurveOps {
     if (rc) return rc;
     u32* r_xy = (u32*)c->ecdsa_ws;
     uint8_t* r_inf = (uint8_t*)c->ecdsa_ws + sz_p;
-    if ((rc = lincomb(c, k, nullptr, FMT_AFFINE, 1, r_xy, FMT_AFFINE, r_inf, n, 0))) return rc;
+    // ECGPU_EXACT_REFERENCE selects the reference's mul_by_generator schedule (complete formulas, full table scans)
+    if ((rc = lincomb(c, k, nullptr, FMT_AFFINE, 1, r_xy, FMT_AFFINE, r_inf, n, flags & ECGPU_EXACT_REFERENCE))) return rc;
     hipLaunchKernelGGL((ecdsa::sign_finish_kernel<C, 16>), dim3(ecgpu_grid_for(c, (n + 15) / 16, 4)), dim3(256), 0, c->stream, d, k, z,
                        (const u32*)r_xy, (const uint8_t*)r_inf, sig, recid, ok, n, flags);
     HIPCHK(c, hipGetLastError());

@@ -63,6 +63,9 @@ def test_sign_kats_and_roundtrip(ctx, cn, ref_vectors):
         assert rec[i] == want[2]
     q = b"".join(bytes.fromhex(v["q_x"]) + bytes.fromhex(v["q_y"]) for v in vs)
     assert cv.ecdsa_verify(z, sig, q, flags=0).all()
+    import ecgpu
+    sig_ref, rec_ref, ok_ref = cv.ecdsa_sign(d, k, z, flags=ecgpu.EXACT_REFERENCE)      # reference schedule for k G: same values
+    assert bytes(sig_ref) == bytes(sig) and bytes(rec_ref) == bytes(rec) and ok_ref.all()
     # k256 low-s behaviour (k256/src/ecdsa.rs:182-207)
     if cn == "k256":
         sig2, rec2, ok2 = cv.ecdsa_sign(d, k, z)
