@@ -265,6 +265,12 @@ class Curve:
     def mul_by_generator(self, scalars, out_format: int = AFFINE, flags: int = 0):
         return self.lincomb(scalars, None, 1, AFFINE, out_format, flags)
 
+    def diffie_hellman(self, secret_scalars, public_keys_xy) -> np.ndarray:
+        """elliptic_curve::ecdh::diffie_hellman for a batch: SharedSecret = x((public * secret).to_affine())
+        (k256/src/ecdh.rs:41-45).  Inputs are what the reference's types guarantee: non-zero scalars, valid keys."""
+        out, _ = self.mul(secret_scalars, public_keys_xy)
+        return np.ascontiguousarray(out[:, :self.nb])
+
     def mul_device(self, d_scalars, d_points, d_out, n: int, point_format: int = AFFINE, out_format: int = AFFINE,
                    d_out_inf=None, flags: int = 0):
         self.ctx.check(self.ctx.lib.ecgpu_mul_batch(self.ctx.handle, self.id, _ptr(d_scalars)[0], _ptr(d_points)[0], point_format,

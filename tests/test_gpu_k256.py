@@ -273,3 +273,19 @@ def test_lincomb_many_terms(cn):
     with pytest.raises(ecgpu.EcgpuError):
         cv.lincomb(sb, pb, terms=16, flags=ecgpu.EXACT_REFERENCE)
     ctx.close()
+
+
+def test_diffie_hellman_agreement(curve):
+    """Both sides of an ECDH exchange derive the same shared secret; value checked against the model."""
+    rng = random.Random(25519)
+    n = 64
+    a = [rng.randrange(1, M.K256.n) for _ in range(n)]
+    b = [rng.randrange(1, M.K256.n) for _ in range(n)]
+    tob = lambda v: v.to_bytes(32, "big")
+    pa, _ = curve.mul_by_generator(b"".join(map(tob, a)))
+    pb, _ = curve.mul_by_generator(b"".join(map(tob, b)))
+    s1 = curve.diffie_hellman(b"".join(map(tob, a)), pb)
+    s2 = curve.diffie_hellman(b"".join(map(tob, b)), pa)
+    assert bytes(s1) == bytes(s2)
+    want = M.affine_mul(M.K256, a[0] * b[0] % M.K256.n, (M.K256.gx, M.K256.gy))[0]
+    assert bytes(s1[0]) == tob(want)
