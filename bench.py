@@ -56,8 +56,8 @@ WORKLOADS = {
                            modmul=None, mac=64, bytes_per_unit=32 + 64 + 65, kernel=None,
                            desc="k256 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
     "p256_fixedbase": dict(curve="p256", cid=1, log2n=24, fixed=True, msm=False, metric="p256 fixed-base (mul_by_generator) scalar-muls/sec", unit="scalar-muls/s",
-                           # batches >= 2^21: 13 signed 20-bit windows -> 13 mixed additions (8M+3S) + batched normalise 6M+1S + (256S+128M)/16
-                           modmul=13 * 11 + 7 + 24, mac=64, bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,20,16,4>",
+                           # batches >= 2^21: 13 signed 20-bit windows -> 13 mixed additions (8M+3S) + batched normalise 6M+1S + (256S+128M)/64
+                           modmul=13 * 11 + 7 + 6, mac=64, bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,20,64,4>",
                            desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
     "p384_varbase":   dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
                            # 96 windows x (4 doublings (4M+4S) + 15/16 mixed additions (8M+3S)) + table (4 dbl + 3 add = 80) + its share of the
@@ -69,13 +69,13 @@ WORKLOADS = {
                            modmul=16 * 11, mac=64, bytes_per_unit=32 + 64, kernel="msm::bucket_sum_kernel (+ digits/scan/scatter/reduce)",
                            desc="k256 multi-scalar multiplication, 2^%d terms per GPU (one sum; ranks exchange one point each), affine output"),
     # ECDSA verification: prep (scalar field) -> u1 G (16-bit fixed-base table) -> u2 Q (the headline
-    # kernel) -> inversion-free check.  Field modmuls: 1764 + 174 + 7; scalar-field work (27 dense Montgomery products of
+    # kernel) -> inversion-free check.  Field modmuls: 1764 + 156 + 7; scalar-field work (27 dense Montgomery products of
     # 136 MACs per signature) is folded in as 57 modmul equivalents.
     "k256_ecdsa_verify": dict(curve="k256", cid=0, log2n=22, fixed=False, msm=False, ecdsa=True, metric="k256 ECDSA verifications/sec", unit="verifications/s",
-                           modmul=1764 + 174 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + k256_mul_fast_kernel<16,4> + verify_check",
+                           modmul=1764 + 156 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + k256_mul_fast_kernel<16,4> + verify_check",
                            desc="k256 ECDSA verify_prehashed (low-s rule), 2^%d independent (prehash, signature, public key) triples per GPU"),
     "p256_ecdsa_verify": dict(curve="p256", cid=1, log2n=22, fixed=False, msm=False, ecdsa=True, metric="p256 ECDSA verifications/sec", unit="verifications/s",
-                           modmul=3160 + 174 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + vb::mul_kernel<CurveP256,8,4> + verify_check",
+                           modmul=3160 + 156 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + vb::mul_kernel<CurveP256,8,4> + verify_check",
                            desc="p256 ECDSA verify_prehashed, 2^%d independent (prehash, signature, public key) triples per GPU"),
 }
 # v_mad_u64_u32 issues at half the FP32-FMA rate on gfx950 (measured, tools/ubench/valu_rates.hip):

@@ -8,6 +8,13 @@
 #include "sec1_kernels.hpp"
 #include "schnorr_kernels.hpp"
 #include "h2c_kernels.hpp"
+// Results per lane that share one inversion in the wide fixed-base kernels.  With only 12-16 additions per result
+// the inversion's share is large: measured at 2^24 scalars, batch 16 / 32 / 64: p256 0.96 / 1.03 / 1.06, k256 1.19 /
+// 1.24 / 1.25 x 10^9 per second; p384 (2^22) 282 / 280 / 279 x 10^6 (its results are 144 bytes each in the private
+// segment), hence 16 there.
+#ifndef FB_BATCH
+#define FB_BATCH (C::NW > 8 ? 16 : 64)
+#endif
 
 namespace ecgpu {
 
@@ -103,14 +110,14 @@ struct CurveOps {
     const int wb = forced ? forced : (n >= ((size_t)1 << 21) ? 20 : n >= ((size_t)1 << 18) ? 16 : 8);
     if (wb == 20) {
       if ((rc = ensure_fb_wide_table<20>(c, &c->fb20_table[C::ID]))) return rc;
-      hipLaunchKernelGGL((fb::mul_wide_kernel<C, 20, 16, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
+      hipLaunchKernelGGL((fb::mul_wide_kernel<C, 20, FB_BATCH, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
                          (const AffEntry<C>*)c->fb20_table[C::ID], out, out_fmt, out_inf, n);
       HIPCHK(c, hipGetLastError());
       return 1;
     }
     if (wb == 16) {
       if ((rc = ensure_fb_wide_table<16>(c, &c->fb16_table[C::ID]))) return rc;
-      hipLaunchKernelGGL((fb::mul_wide_kernel<C, 16, 16, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
+      hipLaunchKernelGGL((fb::mul_wide_kernel<C, 16, FB_BATCH, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
                          (const AffEntry<C>*)c->fb16_table[C::ID], out, out_fmt, out_inf, n);
       HIPCHK(c, hipGetLastError());
       return 1;
