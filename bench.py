@@ -72,7 +72,7 @@ WORKLOADS = {
     # kernel) -> inversion-free check.  Field modmuls: 1764 + 156 + 7; scalar-field work (27 dense Montgomery products of
     # 136 MACs per signature) is folded in as 57 modmul equivalents.
     "k256_ecdsa_verify": dict(curve="k256", cid=0, log2n=22, fixed=False, msm=False, ecdsa=True, metric="k256 ECDSA verifications/sec", unit="verifications/s",
-                           modmul=1764 + 156 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + k256_mul_fast_kernel<16,4> + verify_check",
+                           modmul=1764 + 156 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + k256_mul_fast_kernel<32,4> + verify_check",
                            desc="k256 ECDSA verify_prehashed (low-s rule), 2^%d independent (prehash, signature, public key) triples per GPU"),
     "p256_ecdsa_verify": dict(curve="p256", cid=1, log2n=22, fixed=False, msm=False, ecdsa=True, metric="p256 ECDSA verifications/sec", unit="verifications/s",
                            modmul=3160 + 156 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + vb::mul_kernel<CurveP256,8,4> + verify_check",
@@ -369,7 +369,7 @@ def main():
             "roofline": {
                 "bound": "valu", "achieved": achieved_tmacs, "peak": PEAK_TMACS, "unit": "TMAC/s (32x32+64 v_mad_u64_u32)",
                 "frac": achieved_tmacs / PEAK_TMACS, "traffic": traffic,
-                "kernel": wl["kernel"] or ("lincomb_ref_kernel<CurveK256,1>" if args.schedule == "ref" else "k256_mul_fast_kernel<16,4>"), "kernel_ms": kernel_s * 1e3,
+                "kernel": wl["kernel"] or ("lincomb_ref_kernel<CurveK256,1>" if args.schedule == "ref" else "k256_mul_fast_kernel<32,4>"), "kernel_ms": kernel_s * 1e3,
                 "modmul_per_unit": modmul, "mac_per_unit": modmul * wl["mac"],
                 "mac_pair_peak": MAC_PAIR_PEAK_TMACS, "frac_of_mac_pair_peak": achieved_tmacs / MAC_PAIR_PEAK_TMACS,
                 "hbm": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -2,6 +2,9 @@
 #include "curve_ops.hpp"
 #include "msm_kernels.hpp"
 using namespace ecgpu;
+#ifndef K256_FAST_BATCH
+#define K256_FAST_BATCH 32   // results per lane that share one inversion in the variable-base kernel (16: -0.4 %)
+#endif
 #ifndef MSM_BUCKET_WGS_PER_CU
 #define MSM_BUCKET_WGS_PER_CU 8      // bucket-sum workgroups per CU: lanes then take two or three buckets each (measured 4 / 8 / 16: 16.7 / 16.0 / 16.2 ms)
 #endif
@@ -29,9 +32,9 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
     return 1;
   }
   if (waves == 3)
-    hipLaunchKernelGGL((k256_mul_fast_kernel<16, 3>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
+    hipLaunchKernelGGL((k256_mul_fast_kernel<K256_FAST_BATCH, 3>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
   else
-    hipLaunchKernelGGL((k256_mul_fast_kernel<16, 4>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
+    hipLaunchKernelGGL((k256_mul_fast_kernel<K256_FAST_BATCH, 4>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
   HIPCHK(c, hipGetLastError());
   return 1;
 }
