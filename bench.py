@@ -39,11 +39,11 @@ SEED = 0xEC5CA1A5
 MODMUL_PER_UNIT = {
     # reference schedule: 128 doublings (6M+2S) + 80 additions (12M) + to_affine (255S + 17M)
     "k256_varbase_ref": 128 * 8 + 80 * 12 + 272,
-    # throughput schedule (csrc/mulfast_k256.hpp): Jacobian, common-Z table, batched inversion (batch 16)
+    # throughput schedule (csrc/mulfast_k256.hpp): Jacobian, common-Z table, batched inversion (batch 32)
     #   table   : 1 dbl (3M+4S) + 6 mixed adds (8M+3S) + rescale 7M + 7x(3M+1S) + 8 beta*x  =  87M + 29S
     #   loop    : 128 dbl (3M+4S) + 66 mixed adds (8M+3S)                                   = 912M + 710S
-    #   output  : 2M (global Z) + batched normalise 6M+1S + (255S+15M)/16                   =   9M +  17S
-    "k256_varbase_fast": (87 + 912 + 9) + (29 + 710 + 17),
+    #   output  : 2M (global Z) + batched normalise 6M+1S + (255S+15M)/32                   =   9M +   9S
+    "k256_varbase_fast": (87 + 912 + 9) + (29 + 710 + 9),
 }
 MAC_PER_MODMUL = 64
 BYTES_PER_UNIT = 32 + 64 + 65          # scalar + affine point in, x||y||inf out
@@ -69,10 +69,10 @@ WORKLOADS = {
                            modmul=16 * 11, mac=64, bytes_per_unit=32 + 64, kernel="msm::bucket_sum_kernel (+ digits/scan/scatter/reduce)",
                            desc="k256 multi-scalar multiplication, 2^%d terms per GPU (one sum; ranks exchange one point each), affine output"),
     # ECDSA verification: prep (scalar field) -> u1 G (16-bit fixed-base table) -> u2 Q (the headline
-    # kernel) -> inversion-free check.  Field modmuls: 1764 + 156 + 7; scalar-field work (27 dense Montgomery products of
+    # kernel) -> inversion-free check.  Field modmuls: 1756 + 156 + 7; scalar-field work (27 dense Montgomery products of
     # 136 MACs per signature) is folded in as 57 modmul equivalents.
     "k256_ecdsa_verify": dict(curve="k256", cid=0, log2n=22, fixed=False, msm=False, ecdsa=True, metric="k256 ECDSA verifications/sec", unit="verifications/s",
-                           modmul=1764 + 156 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + k256_mul_fast_kernel<32,4> + verify_check",
+                           modmul=1756 + 156 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + k256_mul_fast_kernel<32,4> + verify_check",
                            desc="k256 ECDSA verify_prehashed (low-s rule), 2^%d independent (prehash, signature, public key) triples per GPU"),
     "p256_ecdsa_verify": dict(curve="p256", cid=1, log2n=22, fixed=False, msm=False, ecdsa=True, metric="p256 ECDSA verifications/sec", unit="verifications/s",
                            modmul=3160 + 156 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + vb::mul_kernel<CurveP256,8,4> + verify_check",
