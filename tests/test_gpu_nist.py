@@ -315,3 +315,24 @@ def test_hash_to_curve(ctx, cn, ref_vectors):
         else:
             assert f == 0 and bytes(g) == M.i2b(c, S[0]) + M.i2b(c, S[1])
     assert inf[-1] == 1
+
+
+@pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1), ("p384", 2)])
+def test_fixed_base_wide_tables_ragged_sizes(ctx, cn, cid):
+    """The wide fixed-base kernels keep up to 64 results per lane for one shared inversion: batch sizes that are not
+    multiples of anything (2^18 + 333 -> 16-bit windows, 2^21 + 777 -> 20-bit windows), head and tail against the C oracle."""
+    import torch
+    cv = ctx.curve(cn)
+    nb = cv.nb
+    for n in ((1 << 18) + 333, (1 << 21) + 777):
+        d_s = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
+        d_o = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+        d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
+        cv.synth_scalars_device(d_s, n, synth.SEED, 99 + n)
+        cv.mul_device(d_s, None, d_o, n, d_out_inf=d_i)
+        ctx.synchronize()
+        idx = np.concatenate([np.arange(0, 200), np.arange(n - 200, n), np.arange(1000, n, n // 97)])
+        s = d_s.cpu().numpy()[idx].copy()
+        want = CO.lincomb_batch(cid, s, None, threads=4)
+        got = np.concatenate([d_o.cpu().numpy()[idx], d_i.cpu().numpy()[idx][:, None]], axis=1)
+        assert bytes(got) == bytes(want), n
