@@ -80,17 +80,31 @@ enum {
    * 4-bit window for p256/p384) so that a PROJECTIVE result is the very (X, Y, Z) triple the
    * reference returns.  Without it the library is free to pick the fastest schedule and only
    * the group element (hence the affine result) is specified. */
+  /* The reference schedule is also its constant-time one: table entries are picked by the reference's masked scan over
+   * the whole table (k256 mul.rs:92-127, primeorder projective.rs:132-137), formulas are complete, and nothing - no
+   * branch, no address - depends on a digit of the scalar.  It is the schedule to use for secret scalars (ECDH, signing
+   * nonces); staged host copies of the scalars are cleared before the call returns.  One caveat, stated rather than
+   * hidden: the field additions and the final fold of a multiplication take a rare carry path (probability ~2^-26 to
+   * 2^-32 per operation on uniformly distributed values) as a real branch, where the reference's 5x52 limbs need none.
+   * The throughput schedules (default for ecgpu_mul_batch / ecgpu_lincomb_batch / ecgpu_msm) skip zero digits, index
+   * tables by digits and branch on exceptional cases: bulk PUBLIC data only. */
   ECGPU_EXACT_REFERENCE = 1u,
   /* ECDSA on secp256k1 as the reference configures it: verification rejects s > n/2
    * (k256/src/ecdsa.rs:199-207), signing normalises s to the low half and flips the recovery
    * parity (k256/src/ecdsa.rs:182-196).  The NIST curves are used without it. */
-  ECGPU_ECDSA_LOW_S = 2u
+  ECGPU_ECDSA_LOW_S = 2u,
+  /* ecgpu_ecdsa_sign_batch only: the nonces are not secret (test vectors, benchmarks, deterministic replays of public
+   * data), so k G may run on the throughput fixed-base schedule (digit-indexed table reads, ~4x faster).  Without it
+   * signing uses the constant-time reference schedule for k G. */
+  ECGPU_PUBLIC_SCALARS = 4u
 };
 
 /* ---- context ------------------------------------------------------------------------------ */
 int ecgpu_create(ecgpu_ctx** ctx, int device_index);
 void ecgpu_destroy(ecgpu_ctx* ctx);
-/* Use the caller's HIP stream (hipStream_t) for all launches; NULL = the context's own stream. */
+/* Use the caller's HIP stream (hipStream_t) for all launches; NULL = the context's own stream.  Calls on one context
+ * share its scratch buffers and lazily built tables, so they are serialised by the context's lock and, across a stream
+ * switch, by an event: everything queued on the previous stream is ordered before anything queued on the new one. */
 int ecgpu_set_stream(ecgpu_ctx* ctx, void* hip_stream);
 int ecgpu_synchronize(ecgpu_ctx* ctx);
 const char* ecgpu_last_error(const ecgpu_ctx* ctx);
@@ -123,6 +137,12 @@ int ecgpu_point_add_mixed_batch(ecgpu_ctx* ctx, int curve, const uint8_t* p_xyz,
 int ecgpu_point_double_batch(ecgpu_ctx* ctx, int curve, const uint8_t* p_xyz, uint8_t* out_xyz,
                              size_t n, int mem);
 
+/* ConstantTimeEq / PartialEq for ProjectivePoint (k256 projective.rs:421-446: cross-multiplied coordinates;
+ * primeorder projective.rs:191-198: equality of the affine forms): eq[i] = 1 iff p[i] and q[i] are the same group
+ * element, whatever their representatives. */
+int ecgpu_point_eq_batch(ecgpu_ctx* ctx, int curve, const uint8_t* p_xyz, const uint8_t* q_xyz, uint8_t* eq,
+                         size_t n, int mem);
+
 /* BatchNormalize::batch_normalize / to_affine (k256 projective.rs:73-84, :325-379; primeorder
  * projective.rs:62-74, :346-413): out_xy[i] = affine(p[i]); out_inf may be NULL. */
 int ecgpu_batch_normalize(ecgpu_ctx* ctx, int curve, const uint8_t* p_xyz, uint8_t* out_xy,
@@ -137,6 +157,15 @@ int ecgpu_mul_batch(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uin
                     int point_format, uint8_t* out, int out_format, uint8_t* out_inf, size_t n,
                     int mem, unsigned flags);
 
+/* Scalars are taken as `Reduce<U256>::reduce` takes them (one conditional subtraction of n, k256 scalar.rs:700-713):
+ * the arithmetic never fails.  Scalar::from_repr instead REJECTS values >= n (k256 scalar.rs:365-368); callers that
+ * decode untrusted scalars use the *_checked forms, which also fill scalar_ok[i] = 1 iff every scalar of element i is
+ * below n (CtOption::is_some); out[i] of an element with scalar_ok[i] = 0 is the result for the reduced scalar and is
+ * to be discarded. */
+int ecgpu_mul_batch_checked(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points,
+                            int point_format, uint8_t* out, int out_format, uint8_t* out_inf, uint8_t* scalar_ok,
+                            size_t n, int mem, unsigned flags);
+
 /* n independent linear combinations of `terms` terms each:
  *   out[i] = sum_j scalars[i*terms + j] * points[i*terms + j]
  * terms = 1, 2: throughput or exact-reference schedules as for ecgpu_mul_batch.  3 <= terms <= 1024: one reference
@@ -147,6 +176,10 @@ int ecgpu_mul_batch(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uin
 int ecgpu_lincomb_batch(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points,
                         int point_format, size_t terms, uint8_t* out, int out_format, uint8_t* out_inf,
                         size_t n, int mem, unsigned flags);
+
+int ecgpu_lincomb_batch_checked(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points,
+                                int point_format, size_t terms, uint8_t* out, int out_format, uint8_t* out_inf,
+                                uint8_t* scalar_ok, size_t n, int mem, unsigned flags);
 
 /* One multi-scalar multiplication out = sum_i scalars[i] * points[i] over n terms (Pippenger
  * bucket method; the large-N form of lincomb_ext over a slice, k256 mul.rs:325-340).
@@ -190,9 +223,10 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* prehash, 
 /* sig_rs[i] = (r, s) with R = k G, r = x(R) mod n, s = k^-1 (z + r d) mod n; recovery_id[i] (optional) =
  * y_is_odd(R) | x_is_reduced << 1; ok[i] = 0 (and a zero signature) when d or k is outside [1, n-1]
  * or r = 0 or s = 0, where the reference returns Err.
- * Note: k G runs on the throughput fixed-base schedule (table lookups and branches indexed by digits of k); unlike the
- * reference's mul_by_generator it is not constant-time.  The values are identical; whether that matters depends on
- * who shares the device; ECGPU_EXACT_REFERENCE in `flags` selects the reference's schedule for k G instead. */
+ * k G runs on the reference's mul_by_generator schedule with its constant-time table scans (see
+ * ECGPU_EXACT_REFERENCE) because the nonce is secret; ECGPU_PUBLIC_SCALARS in `flags` opts into the throughput
+ * fixed-base schedule.  The signatures are identical either way.  Staged host copies of d and k are cleared before
+ * the call returns. */
 int ecgpu_ecdsa_sign_batch(ecgpu_ctx* ctx, int curve, const uint8_t* secret_d, const uint8_t* nonce_k,
                            const uint8_t* prehash, uint8_t* sig_rs, uint8_t* recovery_id, uint8_t* ok,
                            size_t n, int mem, unsigned flags);

@@ -146,8 +146,9 @@ ECGPU_HD void curve_rhs(Fe<P>& r, const Fe<P>& x) {
 }
 
 // ProjectivePoint::mul (primeorder/src/projective.rs:106-150).  k: canonical scalar, little-endian
-// 32-bit limbs; pc: scratch for the 16-entry table.  The table entry is read with the lane's own
-// index instead of the constant-time scan (independent lanes, public bulk data).
+// 32-bit limbs; pc: scratch for the 16-entry table.  The window's entry is picked by the reference's constant-time
+// scan (:132-137): entries 1..15 are all read and merged under an arithmetic mask, so neither the addresses touched
+// nor the instructions executed depend on the scalar.
 template <class P>
 ECGPU_HD void mul_ref(PtNist<P>& q, const PtNist<P>& p, const u32* k, PtNist<P>* pc) {
   constexpr int N = P::Mod::N;
@@ -165,7 +166,20 @@ ECGPU_HD void mul_ref(PtNist<P>& q, const PtNist<P>& p, const u32* k, PtNist<P>*
 #pragma unroll
     for (int j = 1; j < N; j++) w = (pos >> 5) == j ? k[j] : w;
     const u32 slot = (w >> (pos & 31)) & 0xFu;
-    PtNist<P> t = pc[slot];
+    PtNist<P> t;
+    pt_identity<P>(t);
+#pragma unroll 1
+    for (u32 i = 1; i < 16; i++) {
+      const u32 m = 0u - (((slot ^ i) - 1u) >> 31);          // all ones iff slot == i
+      const PtNist<P>& c = pc[i];
+      ECGPU_TABLE_TOUCH(i);
+#pragma unroll
+      for (int w = 0; w < N; w++) {
+        t.x.v[w] = (t.x.v[w] & ~m) | (c.x.v[w] & m);
+        t.y.v[w] = (t.y.v[w] & ~m) | (c.y.v[w] & m);
+        t.z.v[w] = (t.z.v[w] & ~m) | (c.z.v[w] & m);
+      }
+    }
     pt_add<P>(q, q, t);
     if (pos != 0) {
 #pragma unroll 1

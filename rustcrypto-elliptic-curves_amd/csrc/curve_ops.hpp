@@ -53,6 +53,7 @@ struct CurveOps {
     HIPCHK(c, hipMalloc(&t, sizeof(typename C::Pt) * C::GEN_TABLE_PTS));
     hipLaunchKernelGGL((gen_table_kernel<C>), dim3(1), dim3(64), 0, c->stream, (typename C::Pt*)t);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // later calls may run on another stream (ecgpu_set_stream)
     c->gen_table[C::ID] = t;
     return 0;
   }
@@ -161,8 +162,13 @@ struct CurveOps {
     return 0;
   }
   static int msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt);
-  static int validate_scalars(ecgpu_ctx* c, const u32* sc, uint8_t* ok, size_t n) {
-    hipLaunchKernelGGL((validate_scalars_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, sc, ok, n);
+  static int point_eq(ecgpu_ctx* c, const u32* p, const u32* q, uint8_t* eq, size_t n) {
+    hipLaunchKernelGGL((point_eq_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, p, q, eq, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  static int validate_scalars(ecgpu_ctx* c, const u32* sc, uint8_t* ok, size_t n, size_t terms) {
+    hipLaunchKernelGGL((validate_scalars_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, sc, ok, n, terms);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
@@ -298,15 +304,17 @@ struct CurveOps {
     if (rc) return rc;
     u32* r_xy = (u32*)c->ecdsa_ws;
     uint8_t* r_inf = (uint8_t*)c->ecdsa_ws + sz_p;
-    // ECGPU_EXACT_REFERENCE selects the reference's mul_by_generator schedule (complete formulas, full table scans)
-    if ((rc = lincomb(c, k, nullptr, FMT_AFFINE, 1, r_xy, FMT_AFFINE, r_inf, n, flags & ECGPU_EXACT_REFERENCE))) return rc;
+    // The nonce is secret: k G runs on the reference's mul_by_generator schedule (complete formulas, constant-time
+    // table scans, no digit-dependent branch or address) unless the caller declares the scalars public.
+    if ((rc = lincomb(c, k, nullptr, FMT_AFFINE, 1, r_xy, FMT_AFFINE, r_inf, n, (flags & ECGPU_PUBLIC_SCALARS) ? 0u : (unsigned)ECGPU_EXACT_REFERENCE)))
+      return rc;
     hipLaunchKernelGGL((ecdsa::sign_finish_kernel<C, 16>), dim3(ecgpu_grid_for(c, (n + 15) / 16, 4)), dim3(256), 0, c->stream, d, k, z,
                        (const u32*)r_xy, (const uint8_t*)r_inf, sig, recid, ok, n, flags);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
   static const ecgpu_curve_ops* table() {
-    static const ecgpu_curve_ops t = {field_op, point_op, normalize, lincomb, msm, validate_scalars, validate_points,
+    static const ecgpu_curve_ops t = {field_op, point_op, point_eq, normalize, lincomb, msm, validate_scalars, validate_points,
                                       decompress, synth_scalars, synth_points, to_bytes, from_bytes, ecdsa_verify, h2c_map, ecdsa_recover, schnorr_verify, ecdsa_sign};
     return &t;
   }

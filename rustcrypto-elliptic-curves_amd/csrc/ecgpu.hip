@@ -183,7 +183,8 @@ int ecgpu_create(ecgpu_ctx** out, int device_index) {
   c->device = device_index;
   c->num_cus = prop.multiProcessorCount;
   if (hipSetDevice(device_index) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return ECGPU_ERR_RUNTIME;
   }
@@ -196,7 +197,11 @@ void ecgpu_destroy(ecgpu_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (int i = 0; i < ecgpu_ctx::NSTAGE; i++) if (c->stage[i]) (void)hipFree(c->stage[i]);
+  for (int i = 0; i < ecgpu_ctx::NSTAGE; i++)
+    if (c->stage[i]) {                       // staging slots may have held secret scalars: clear before release
+      (void)hipMemset(c->stage[i], 0, c->stage_cap[i]);
+      (void)hipFree(c->stage[i]);
+    }
   for (int i = 0; i < 2; i++) if (c->ev_kernel[i]) (void)hipEventDestroy(c->ev_kernel[i]);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   for (int i = 0; i < 3; i++) if (c->gen_table[i]) (void)hipFree(c->gen_table[i]);
@@ -208,17 +213,29 @@ void ecgpu_destroy(ecgpu_ctx* c) {
   if (c->ecdsa_ws) (void)hipFree(c->ecdsa_ws);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
+// The per-context scratch (staging slots, table / MSM / ECDSA workspaces, lazily built tables) is shared by
+// consecutive calls, so work queued on the old stream must be ordered before anything the new stream does:
+// an event recorded on the old stream is waited for by the new one.
 int ecgpu_set_stream(ecgpu_ctx* c, void* s) {
   if (!c) return ECGPU_ERR_ARG;
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t next = s ? (hipStream_t)s : c->own_stream;
+  if (next == c->stream) return ECGPU_OK;
+  HIPCHK(c, hipEventRecord(c->ev_switch, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(next, c->ev_switch, 0));
+  c->stream = next;
   return ECGPU_OK;
 }
 int ecgpu_synchronize(ecgpu_ctx* c) {
   if (!c) return ECGPU_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ECGPU_OK;
 }
@@ -243,11 +260,15 @@ int ecgpu_host_free(ecgpu_ctx* c, void* p) {
 
 int ecgpu_timer_start(ecgpu_ctx* c) {
   if (!c) return ECGPU_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   return ECGPU_OK;
 }
 int ecgpu_timer_stop(ecgpu_ctx* c, float* ms) {
   if (!c || !ms) return ECGPU_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipEventSynchronize(c->ev1));
   HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -294,6 +315,20 @@ int ecgpu_point_double_batch(ecgpu_ctx* c, int curve, const uint8_t* p, uint8_t*
   return point_op(c, curve, 2, p, nullptr, 0, out, n, mem);
 }
 
+int ecgpu_point_eq_batch(ecgpu_ctx* c, int curve, const uint8_t* p, const uint8_t* q, uint8_t* eq, size_t n, int mem) {
+  if (!c || !p || !q || !eq) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (n == 0) return ECGPU_OK;
+  ENTER(c, curve);
+  Buf bp, bq, bo;
+  int rc;
+  if ((rc = buf_in(c, bp, 0, p, n * 3 * nb, mem))) return rc;
+  if ((rc = buf_in(c, bq, 1, q, n * 3 * nb, mem))) return rc;
+  if ((rc = buf_out(c, bo, 2, eq, n, mem))) return rc;
+  if ((rc = ops->point_eq(c, (const uint32_t*)bp.dev, (const uint32_t*)bq.dev, (uint8_t*)bo.dev, n))) return rc;
+  if ((rc = buf_finish(c, bo))) return rc;
+  return finish_host(c, mem);
+}
+
 int ecgpu_batch_normalize(ecgpu_ctx* c, int curve, const uint8_t* p, uint8_t* out_xy, uint8_t* out_inf, size_t n, int mem) {
   if (!c || !p || !out_xy) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
   if (n == 0) return ECGPU_OK;
@@ -309,8 +344,14 @@ int ecgpu_batch_normalize(ecgpu_ctx* c, int curve, const uint8_t* p, uint8_t* ou
   return finish_host(c, mem);
 }
 
-int ecgpu_lincomb_batch(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t terms,
-                        uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, int mem, unsigned flags) {
+// clear a staging slot that held secret scalars (ordered after the kernels that read it)
+static int wipe_stage(ecgpu_ctx* c, int slot) {
+  if (c->stage[slot] && c->stage_cap[slot]) HIPCHK(c, hipMemsetAsync(c->stage[slot], 0, c->stage_cap[slot], c->stream));
+  return 0;
+}
+
+static int lincomb_impl(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t terms, uint8_t* out, int out_fmt,
+                        uint8_t* out_inf, uint8_t* scalar_ok, size_t n, int mem, unsigned flags) {
   if (!c || !scalars || !out) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
   if ((pt_fmt != ECGPU_PT_AFFINE && pt_fmt != ECGPU_PT_PROJECTIVE) || (out_fmt != ECGPU_PT_AFFINE && out_fmt != ECGPU_PT_PROJECTIVE))
     return ecgpu_set_err(c, ECGPU_ERR_ARG, "bad point format");
@@ -318,41 +359,81 @@ int ecgpu_lincomb_batch(ecgpu_ctx* c, int curve, const uint8_t* scalars, const u
   if (n == 0) return ECGPU_OK;
   ENTER(c, curve);
   const size_t pin = (pt_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb, pout = (out_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb;
+  // the reference schedule is the one meant for secret scalars: their staged copies do not outlive the call
+  const bool secret = (flags & ECGPU_EXACT_REFERENCE) != 0;
   if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
-    const PipeArg args[4] = {{scalars, nullptr, terms * nb}, {points, nullptr, points ? terms * pin : 0}, {nullptr, out, pout},
-                             {nullptr, out_fmt == ECGPU_PT_AFFINE ? out_inf : nullptr, 1}};
-    return host_pipeline(c, args, 4, n, [&](void** d, size_t cnt) {
+    const PipeArg args[5] = {{scalars, nullptr, terms * nb}, {points, nullptr, points ? terms * pin : 0}, {nullptr, out, pout},
+                             {nullptr, out_fmt == ECGPU_PT_AFFINE ? out_inf : nullptr, 1}, {nullptr, scalar_ok, 1}};
+    int rc = host_pipeline(c, args, 5, n, [&](void** d, size_t cnt) {
+      if (d[4]) {
+        int r2 = ops->validate_scalars(c, (const uint32_t*)d[0], (uint8_t*)d[4], cnt, terms);
+        if (r2) return r2;
+      }
       return ops->lincomb(c, (const uint32_t*)d[0], (const uint32_t*)d[1], pt_fmt, terms, (uint32_t*)d[2], out_fmt, (uint8_t*)d[3], cnt, flags);
     });
+    if (secret) {
+      for (int sl = 0; sl < 2; sl++) { int r2 = wipe_stage(c, 6 + sl * PIPE_MAXARGS); if (r2 && !rc) rc = r2; }
+      (void)hipStreamSynchronize(c->stream);
+    }
+    return rc;
   }
-  Buf bs, bp, bo, bi;
+  Buf bs, bp, bo, bi, bk;
   int rc;
   if ((rc = buf_in(c, bs, 0, scalars, n * terms * nb, mem))) return rc;
   if ((rc = buf_in(c, bp, 1, points, n * terms * pin, mem))) return rc;
   if ((rc = buf_out(c, bo, 2, out, n * pout, mem))) return rc;
   if ((rc = buf_out(c, bi, 3, out_fmt == ECGPU_PT_AFFINE ? out_inf : nullptr, n, mem))) return rc;
+  if ((rc = buf_out(c, bk, 5, scalar_ok, n, mem))) return rc;
+  if (bk.dev && (rc = ops->validate_scalars(c, (const uint32_t*)bs.dev, (uint8_t*)bk.dev, n, terms))) return rc;
   if ((rc = ops->lincomb(c, (const uint32_t*)bs.dev, (const uint32_t*)bp.dev, pt_fmt, terms, (uint32_t*)bo.dev, out_fmt,
                          (uint8_t*)bi.dev, n, flags)))
     return rc;
   if ((rc = buf_finish(c, bo))) return rc;
   if ((rc = buf_finish(c, bi))) return rc;
+  if ((rc = buf_finish(c, bk))) return rc;
+  if (secret && mem == ECGPU_MEM_HOST && (rc = wipe_stage(c, 0))) return rc;
   return finish_host(c, mem);
+}
+
+int ecgpu_lincomb_batch(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t terms,
+                        uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, int mem, unsigned flags) {
+  return lincomb_impl(c, curve, scalars, points, pt_fmt, terms, out, out_fmt, out_inf, nullptr, n, mem, flags);
+}
+int ecgpu_lincomb_batch_checked(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t terms,
+                                uint8_t* out, int out_fmt, uint8_t* out_inf, uint8_t* scalar_ok, size_t n, int mem, unsigned flags) {
+  if (!scalar_ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  return lincomb_impl(c, curve, scalars, points, pt_fmt, terms, out, out_fmt, out_inf, scalar_ok, n, mem, flags);
 }
 
 int ecgpu_mul_batch(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt,
                     uint8_t* out_inf, size_t n, int mem, unsigned flags) {
-  return ecgpu_lincomb_batch(c, curve, scalars, points, pt_fmt, 1, out, out_fmt, out_inf, n, mem, flags);
+  return lincomb_impl(c, curve, scalars, points, pt_fmt, 1, out, out_fmt, out_inf, nullptr, n, mem, flags);
+}
+int ecgpu_mul_batch_checked(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt,
+                            uint8_t* out_inf, uint8_t* scalar_ok, size_t n, int mem, unsigned flags) {
+  if (!scalar_ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  return lincomb_impl(c, curve, scalars, points, pt_fmt, 1, out, out_fmt, out_inf, scalar_ok, n, mem, flags);
 }
 
 int ecgpu_msm(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t n, uint8_t* out, int out_fmt,
               int mem) {
-  if (!c || !scalars || !points || !out) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (!c || !out || (n && (!scalars || !points))) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
   if ((pt_fmt != ECGPU_PT_AFFINE && pt_fmt != ECGPU_PT_PROJECTIVE) || (out_fmt != ECGPU_PT_AFFINE && out_fmt != ECGPU_PT_PROJECTIVE))
     return ecgpu_set_err(c, ECGPU_ERR_ARG, "bad point format");
   ENTER(c, curve);
   const size_t pin = (pt_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb, pout = (out_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb;
   Buf bs, bp, bo;
   int rc;
+  if (n == 0) {                              // the empty sum is the identity: affine zeros, projective (0 : 1 : 0)
+    if (mem == ECGPU_MEM_HOST) {
+      memset(out, 0, pout);
+      if (out_fmt == ECGPU_PT_PROJECTIVE) out[2 * nb - 1] = 1;
+      return ECGPU_OK;
+    }
+    HIPCHK(c, hipMemsetAsync(out, 0, pout, c->stream));
+    if (out_fmt == ECGPU_PT_PROJECTIVE) HIPCHK(c, hipMemsetAsync(out + 2 * nb - 1, 1, 1, c->stream));
+    return ECGPU_OK;
+  }
   if ((rc = buf_in(c, bs, 0, scalars, n * nb, mem))) return rc;
   if ((rc = buf_in(c, bp, 1, points, n * pin, mem))) return rc;
   if ((rc = buf_out(c, bo, 2, out, pout, mem))) return rc;
@@ -370,7 +451,7 @@ int ecgpu_validate_scalars(ecgpu_ctx* c, int curve, const uint8_t* scalars, uint
   int rc;
   if ((rc = buf_in(c, bs, 0, scalars, n * nb, mem))) return rc;
   if ((rc = buf_out(c, bo, 2, ok, n, mem))) return rc;
-  if ((rc = ops->validate_scalars(c, (const uint32_t*)bs.dev, (uint8_t*)bo.dev, n))) return rc;
+  if ((rc = ops->validate_scalars(c, (const uint32_t*)bs.dev, (uint8_t*)bo.dev, n, 1))) return rc;
   if ((rc = buf_finish(c, bo))) return rc;
   return finish_host(c, mem);
 }
@@ -521,10 +602,15 @@ int ecgpu_ecdsa_sign_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, con
   if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
     const PipeArg args[6] = {{secret_d, nullptr, nb}, {nonce_k, nullptr, nb}, {prehash, nullptr, nb}, {nullptr, sig_rs, 2 * nb},
                              {nullptr, recovery_id, 1}, {nullptr, ok, 1}};
-    return host_pipeline(c, args, 6, n, [&](void** d, size_t cnt) {
+    int prc = host_pipeline(c, args, 6, n, [&](void** d, size_t cnt) {
       return ops->ecdsa_sign(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (const uint32_t*)d[2], (uint32_t*)d[3], (uint8_t*)d[4], (uint8_t*)d[5], cnt,
                              flags);
     });
+    // the staged copies of the secret keys and nonces do not outlive the call (the reference zeroizes them)
+    for (int sl = 0; sl < 2; sl++)
+      for (int a = 0; a < 2; a++) { int r2 = wipe_stage(c, 6 + sl * PIPE_MAXARGS + a); if (r2 && !prc) prc = r2; }
+    (void)hipStreamSynchronize(c->stream);
+    return prc;
   }
   Buf bd, bk, bz, bs, br, bo;
   int rc;
@@ -540,6 +626,10 @@ int ecgpu_ecdsa_sign_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, con
   if ((rc = buf_finish(c, bs))) return rc;
   if ((rc = buf_finish(c, br))) return rc;
   if ((rc = buf_finish(c, bo))) return rc;
+  if (mem == ECGPU_MEM_HOST) {               // staged secret keys and nonces are cleared (the reference zeroizes them)
+    if ((rc = wipe_stage(c, 0))) return rc;
+    if ((rc = wipe_stage(c, 1))) return rc;
+  }
   return finish_host(c, mem);
 }
 

@@ -16,6 +16,7 @@ struct ecgpu_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_switch = nullptr;            // orders work across ecgpu_set_stream
   char err[512] = {0};
   std::mutex mu;
   // grow-only device staging buffers for ECGPU_MEM_HOST calls
@@ -69,11 +70,12 @@ static inline unsigned ecgpu_grid_for(const ecgpu_ctx* c, size_t n, int per_cu) 
 struct ecgpu_curve_ops {
   int (*field_op)(ecgpu_ctx* c, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n);
   int (*point_op)(ecgpu_ctx* c, int op, const uint32_t* p, const uint32_t* q, uint32_t* out, size_t n);
+  int (*point_eq)(ecgpu_ctx* c, const uint32_t* p, const uint32_t* q, uint8_t* eq, size_t n);
   int (*normalize)(ecgpu_ctx* c, const uint32_t* p, uint32_t* out_xy, uint8_t* out_inf, size_t n);
   int (*lincomb)(ecgpu_ctx* c, const uint32_t* scalars, const uint32_t* points, int pt_fmt, size_t terms, uint32_t* out,
                  int out_fmt, uint8_t* out_inf, size_t n, unsigned flags);
   int (*msm)(ecgpu_ctx* c, const uint32_t* scalars, const uint32_t* points, int pt_fmt, size_t n, uint32_t* out, int out_fmt);
-  int (*validate_scalars)(ecgpu_ctx* c, const uint32_t* scalars, uint8_t* ok, size_t n);
+  int (*validate_scalars)(ecgpu_ctx* c, const uint32_t* scalars, uint8_t* ok, size_t n, size_t terms);
   int (*validate_points)(ecgpu_ctx* c, const uint32_t* xy, uint8_t* ok, size_t n);
   int (*decompress)(ecgpu_ctx* c, const uint32_t* x, const uint8_t* y_is_odd, uint32_t* out_xy, uint8_t* ok, size_t n);
   int (*synth_scalars)(ecgpu_ctx* c, uint64_t seed, uint64_t first, uint32_t* out, size_t n);

@@ -276,40 +276,92 @@ ECGPU_HD void sqr_n(FeMont<M>& r, const FeMont<M>& a, int n) {
   r = a;
   for (int i = 0; i < n; i++) sqr(r, r);
 }
-// r = a^e for a public exponent e (little-endian limbs), square-and-multiply from the top bit
+// acc = acc^(2^k) * m: the step every addition chain below is made of
 template <class M>
-ECGPU_HD void pow_public(FeMont<M>& r, const FeMont<M>& a, const u32* e) {
-  FeMont<M> acc;
-  set_one(acc);
+ECGPU_HD void pow2k_mul(FeMont<M>& acc, int k, const FeMont<M>& m) {
 #pragma unroll 1
-  for (int i = 32 * M::N - 1; i >= 0; i--) {
-    sqr(acc, acc);
-    if ((e[i >> 5] >> (i & 31)) & 1) mul(acc, acc, a);
-  }
-  r = acc;
+  for (int i = 0; i < k; i++) sqr(acc, acc);
+  mul(acc, acc, m);
 }
-// a^(p-2): the unique inverse (p256 field.rs:357-382 uses a fixed chain for the same exponent;
-// p384 uses Bernstein-Yang, p384 field.rs:67-91 - the result is the same field element)
+template <class M>
+ECGPU_HD void pow2k(FeMont<M>& acc, int k) {
+#pragma unroll 1
+  for (int i = 0; i < k; i++) sqr(acc, acc);
+}
+// Fixed addition chains for the two exponents every caller needs, a^(p-2) and a^((p+1)/4).  x<k> stands for
+// a^(2^k - 1), a run of k one bits; x_{j+k} = x_j^(2^k) * x_k.  The exponents written as runs (top bit first):
+//   P-256  p - 2     = [32 ones][31 zeros][1][96 zeros][94 ones][0][1]              255 S + 12 M
+//          (p + 1)/4 = [32 ones][31 zeros][1][95 zeros][1][94 zeros]                253 S +  7 M
+//   P-384  p - 2     = [255 ones][0][32 ones][64 zeros][30 ones][0][1]              385 S + 14 M
+//          (p + 1)/4 = [255 ones][0][32 ones][63 zeros][1][30 zeros]                383 S + 13 M
+// (the generic square-and-multiply they replace cost 256 S + 128 M and 384 S + ~350 M).  Same exponents as
+// p256 field.rs:357-411 and p384 field.rs:95-117; p384's invert is Bernstein-Yang in the reference (field.rs:67-91),
+// the inverse is unique so the field element is the same.
+template <class M>
+ECGPU_HD void p384_runs(FeMont<M>& x255, FeMont<M>& x32, FeMont<M>& x30, const FeMont<M>& a) {
+  FeMont<M> x2, x3, x15, t;
+  sqr(x2, a); mul(x2, x2, a);
+  sqr(x3, x2); mul(x3, x3, a);
+  t = x3; pow2k_mul(t, 3, x3);            // x6
+  x15 = t; pow2k_mul(x15, 6, t);          // x12
+  pow2k_mul(x15, 3, x3);                  // x15
+  x30 = x15; pow2k_mul(x30, 15, x15);
+  x32 = x30; pow2k_mul(x32, 2, x2);
+  t = x30; pow2k_mul(t, 30, x30);         // x60
+  x255 = t; pow2k_mul(x255, 60, t);       // x120
+  t = x255; pow2k_mul(x255, 120, t);      // x240
+  pow2k_mul(x255, 15, x15);
+}
+// a^(p-2): the unique inverse (0 -> 0)
 template <class M>
 ECGPU_HD void inv(FeMont<M>& r, const FeMont<M>& a) {
-  u32 e[M::N];
-#pragma unroll
-  for (int i = 0; i < M::N; i++) e[i] = M::P[i];
-  e[0] -= 2;
-  pow_public(r, a, e);
+  if constexpr (M::N == 8) {
+    FeMont<M> x2, x3, x15, x32, x47, t;
+    sqr(x2, a); mul(x2, x2, a);
+    sqr(x3, x2); mul(x3, x3, a);
+    t = x3; pow2k_mul(t, 3, x3);          // x6
+    x15 = t; pow2k_mul(x15, 6, t);        // x12
+    pow2k_mul(x15, 3, x3);                // x15
+    x32 = x15; pow2k_mul(x32, 1, a);      // x16
+    t = x32; pow2k_mul(x32, 16, t);       // x32
+    t = x32; pow2k(t, 15);                // x32 << 15 (still on the main chain)
+    mul(x47, t, x15);                     // x47 beside it
+    pow2k_mul(t, 17, a);                  // [32 ones][31 zeros][1]
+    pow2k_mul(t, 143, x47);               // [96 zeros][47 ones]
+    pow2k_mul(t, 47, x47);                // [47 ones]
+    pow2k_mul(t, 2, a);                   // [0][1]
+    r = t;
+  } else {
+    FeMont<M> x255, x32, x30;
+    p384_runs(x255, x32, x30, a);
+    pow2k_mul(x255, 33, x32);             // [0][32 ones]
+    pow2k_mul(x255, 94, x30);             // [64 zeros][30 ones]
+    pow2k_mul(x255, 2, a);                // [0][1]
+    r = x255;
+  }
 }
 // a^((p+1)/4) (both primes are 3 mod 4); returns whether it is a square root
-// (p256 field.rs:385-411, p384 field.rs:95-117)
 template <class M>
 ECGPU_HD bool sqrt(FeMont<M>& r, const FeMont<M>& a) {
-  u32 e[M::N + 1];
-  u32 c = 1;
-#pragma unroll
-  for (int i = 0; i < M::N; i++) e[i] = addc(M::P[i], 0u, c);
-  e[M::N] = c;
-#pragma unroll
-  for (int i = 0; i < M::N; i++) e[i] = (e[i] >> 2) | (e[i + 1] << 30);
-  pow_public(r, a, e);
+  FeMont<M> t;
+  if constexpr (M::N == 8) {
+    FeMont<M> u;
+    sqr(t, a); mul(t, t, a);              // x2
+    u = t; pow2k_mul(t, 2, u);            // x4
+    u = t; pow2k_mul(t, 4, u);            // x8
+    u = t; pow2k_mul(t, 8, u);            // x16
+    u = t; pow2k_mul(t, 16, u);           // x32
+    pow2k_mul(t, 32, a);                  // [31 zeros][1]
+    pow2k_mul(t, 96, a);                  // [95 zeros][1]
+    pow2k(t, 94);
+  } else {
+    FeMont<M> x32, x30;
+    p384_runs(t, x32, x30, a);
+    pow2k_mul(t, 33, x32);                // [0][32 ones]
+    pow2k_mul(t, 64, a);                  // [63 zeros][1]
+    pow2k(t, 30);
+  }
+  r = t;
   FeMont<M> chk;
   sqr(chk, r);
   return equal(chk, a);

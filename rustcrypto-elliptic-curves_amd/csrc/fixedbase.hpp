@@ -104,41 +104,7 @@ __global__ void __launch_bounds__(256, WAVES) mul_kernel(const u32* scalars, con
       res[b] = acc;
       cnt = b + 1;
     }
-    // batched conversion to affine and output
-    typename C::Fe acc; C::fe_one(acc);
-#pragma unroll 1
-    for (int b = 0; b < cnt; b++) {
-      pre[b] = acc;
-      typename C::Fe z = res[b].z;
-      if (C::fe_is_zero(z)) C::fe_one(z);
-      C::fe_mul(acc, acc, z);
-    }
-    typename C::Fe ai;
-    C::fe_inv(ai, acc);
-#pragma unroll 1
-    for (int b = cnt - 1; b >= 0; b--) {
-      const size_t i = base + (size_t)b * T;
-      typename C::Fe z = res[b].z, one, zero, zi, t, x, y;
-      C::fe_one(one); C::fe_zero(zero);
-      const bool zr = C::fe_is_zero(z);
-      if (zr) z = one;
-      C::fe_mul(zi, ai, pre[b]);
-      C::fe_mul(ai, ai, z);
-      C::fe_sqr(t, zi);
-      C::fe_mul(x, res[b].x, t);
-      C::fe_mul(t, t, zi);
-      C::fe_mul(y, res[b].y, t);
-      if (zr) { x = zero; y = zero; }
-      if (out_fmt == FMT_PROJECTIVE) {
-        if (zr) y = one;
-        u32* o = out + i * 3 * NW;
-        C::fe_store(o, x); C::fe_store(o + NW, y); C::fe_store(o + 2 * NW, zr ? zero : one);
-      } else {
-        u32* o = out + i * 2 * NW;
-        C::fe_store(o, x); C::fe_store(o + NW, y);
-        if (out_inf) out_inf[i] = zr ? 1 : 0;
-      }
-    }
+    jac::store_batch_affine<C>(res, pre, cnt, base, T, out, out_fmt, out_inf);
   }
 }
 
@@ -248,40 +214,7 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
       res[b] = acc;
       cnt = b + 1;
     }
-    typename C::Fe accz; C::fe_one(accz);
-#pragma unroll 1
-    for (int b = 0; b < cnt; b++) {
-      pre[b] = accz;
-      typename C::Fe z = res[b].z;
-      if (C::fe_is_zero(z)) C::fe_one(z);
-      C::fe_mul(accz, accz, z);
-    }
-    typename C::Fe ai;
-    C::fe_inv(ai, accz);
-#pragma unroll 1
-    for (int b = cnt - 1; b >= 0; b--) {
-      const size_t i = base + (size_t)b * T;
-      typename C::Fe z = res[b].z, one, zero, zi, t, x, y;
-      C::fe_one(one); C::fe_zero(zero);
-      const bool zr = C::fe_is_zero(z);
-      if (zr) z = one;
-      C::fe_mul(zi, ai, pre[b]);
-      C::fe_mul(ai, ai, z);
-      C::fe_sqr(t, zi);
-      C::fe_mul(x, res[b].x, t);
-      C::fe_mul(t, t, zi);
-      C::fe_mul(y, res[b].y, t);
-      if (zr) { x = zero; y = zero; }
-      if (out_fmt == FMT_PROJECTIVE) {
-        if (zr) y = one;
-        u32* o = out + i * 3 * NW;
-        C::fe_store(o, x); C::fe_store(o + NW, y); C::fe_store(o + 2 * NW, zr ? zero : one);
-      } else {
-        u32* o = out + i * 2 * NW;
-        C::fe_store(o, x); C::fe_store(o + NW, y);
-        if (out_inf) out_inf[i] = zr ? 1 : 0;
-      }
-    }
+    jac::store_batch_affine<C>(res, pre, cnt, base, T, out, out_fmt, out_inf);
   }
 }
 

@@ -161,5 +161,51 @@ ECGPU_HD void batch_to_affine(typename C::Fe* ax, typename C::Fe* ay, u32* inf, 
   }
 }
 
+// The shared epilogue of the throughput kernels (BatchNormalize, k256 projective.rs:325-379 / primeorder
+// projective.rs:346-413, applied per lane): the cnt Jacobian results of one lane - element j is global index
+// base + j * stride - go to affine with ONE inversion and are written in the caller's format: affine x || y
+// (+ infinity byte, zeros for the identity) or the homogeneous representative (x : y : 1), identity (0 : 1 : 0).
+// J is any {x, y, z} of C::Fe; `pre` is scratch for cnt field elements.
+template <class C, class J>
+ECGPU_HD void store_batch_affine(const J* res, typename C::Fe* pre, int cnt, size_t base, size_t stride, u32* out, int out_fmt,
+                                 uint8_t* out_inf) {
+  using Fe = typename C::Fe;
+  constexpr int NW = C::NW;
+  Fe acc; C::fe_one(acc);
+#pragma unroll 1
+  for (int j = 0; j < cnt; j++) {
+    pre[j] = acc;
+    Fe z = res[j].z;
+    if (C::fe_is_zero(z)) C::fe_one(z);
+    C::fe_mul(acc, acc, z);
+  }
+  Fe ai;
+  C::fe_inv(ai, acc);
+#pragma unroll 1
+  for (int j = cnt - 1; j >= 0; j--) {
+    const size_t i = base + (size_t)j * stride;
+    Fe z = res[j].z, one, zero, zi, t, x, y;
+    C::fe_one(one); C::fe_zero(zero);
+    const bool zr = C::fe_is_zero(z);
+    if (zr) z = one;
+    C::fe_mul(zi, ai, pre[j]);
+    C::fe_mul(ai, ai, z);
+    C::fe_sqr(t, zi);
+    C::fe_mul(x, res[j].x, t);
+    C::fe_mul(t, t, zi);
+    C::fe_mul(y, res[j].y, t);
+    if (zr) { x = zero; y = zero; }
+    if (out_fmt == FMT_PROJECTIVE) {
+      if (zr) y = one;
+      u32* o = out + i * 3 * NW;
+      C::fe_store(o, x); C::fe_store(o + NW, y); C::fe_store(o + 2 * NW, zr ? zero : one);
+    } else {
+      u32* o = out + i * 2 * NW;
+      C::fe_store(o, x); C::fe_store(o + NW, y);
+      if (out_inf) out_inf[i] = zr ? 1 : 0;
+    }
+  }
+}
+
 }  // namespace jac
 }  // namespace ecgpu

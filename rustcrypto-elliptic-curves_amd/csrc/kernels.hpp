@@ -8,6 +8,7 @@
 #pragma once
 #include "traits.hpp"
 #include "mulfast_k256.hpp"
+#include "jacobian.hpp"
 
 namespace ecgpu {
 
@@ -16,7 +17,6 @@ namespace ecgpu {
 
 enum { FE_MUL = 0, FE_SQR = 1, FE_ADD = 2, FE_SUB = 3, FE_NEG = 4, FE_INV = 5, FE_SQRT = 6 };
 enum { PT_ADD = 0, PT_ADD_MIXED = 1, PT_DOUBLE = 2 };
-enum { FMT_AFFINE = 0, FMT_PROJECTIVE = 1 };
 
 template <class C>
 __device__ __forceinline__ void load_affine(typename C::Af& a, const u32* xy) {
@@ -108,6 +108,23 @@ __global__ void __launch_bounds__(256) point_op_kernel(const u32* p, const u32* 
     }
     if (OP == PT_DOUBLE) C::pt_double(r, a);
     store_projective<C>(out + i * 3 * C::NW, r);
+  }
+}
+
+// ConstantTimeEq / PartialEq of projective points (k256 projective.rs:421-446: X1 Z2 == X2 Z1 and Y1 Z2 == Y2 Z1;
+// primeorder projective.rs:191-198 compares the affine forms - the same relation on valid points).  Two identities
+// are equal, an identity and a finite point are not.
+template <class C>
+__global__ void __launch_bounds__(256) point_eq_kernel(const u32* p, const u32* q, uint8_t* eq, size_t n) {
+  ECGPU_GRID_STRIDE(i, n) {
+    typename C::Pt a, b;
+    load_point<C>(a, p + i * 3 * C::NW, FMT_PROJECTIVE);
+    load_point<C>(b, q + i * 3 * C::NW, FMT_PROJECTIVE);
+    typename C::Fe l, r, d;
+    C::fe_mul(l, a.x, b.z); C::fe_mul(r, b.x, a.z); C::fe_sub(d, l, r);
+    const bool ex = C::fe_is_zero(d);
+    C::fe_mul(l, a.y, b.z); C::fe_mul(r, b.y, a.z); C::fe_sub(d, l, r);
+    eq[i] = (ex && C::fe_is_zero(d)) ? 1 : 0;
   }
 }
 
@@ -215,8 +232,9 @@ __global__ void __launch_bounds__(256) lincomb_sum_kernel(const u32* scalars, co
 //
 // WAVES is the occupancy target handed to the register allocator through __launch_bounds__: left
 // alone it spends 256 VGPRs (+AGPRs) on instruction-level parallelism and ends at one wave per SIMD;
-// with WAVES = 3 it fits 168 VGPRs with two spilled dwords, with WAVES = 4 128 VGPRs and 38 spilled
-// dwords (callable device functions cannot carry an occupancy target, so the phases are inlined).
+// WAVES = 4 gives 128 VGPRs (callable device functions cannot carry an occupancy target, so the phases
+// are inlined).  The spill and scratch figures of the shipped build are in DESIGN.md section 4 (they
+// move with BATCH: the BATCH results and prefix products live in the private segment by design).
 // ---------------------------------------------------------------------------------------------
 struct K256FastPrep {
   u32 y1[4], y2[4];     // recoded magnitudes of the two GLV halves (radix16_recode)
@@ -299,41 +317,7 @@ __device__ __forceinline__ void k256_fast_loop(JacK256* out, const K256FastPrep*
 // Montgomery's trick over the cnt results of this lane; element j of the batch is global index base + j*T.
 __device__ __forceinline__ void k256_fast_finish(const JacK256* res, FeK256* pre, int cnt, size_t base, size_t T, u32* out, int out_fmt,
                                               uint8_t* out_inf) {
-  FeK256 acc; k256::set_one(acc);
-#pragma unroll 1
-  for (int j = 0; j < cnt; j++) {
-    pre[j] = acc;
-    FeK256 z = res[j].z;
-    if (k256::is_zero(z)) k256::set_one(z);
-    k256::mul(acc, acc, z);
-  }
-  FeK256 ai;
-  k256::inv(ai, acc);
-#pragma unroll 1
-  for (int j = cnt - 1; j >= 0; j--) {
-    const size_t i = base + (size_t)j * T;
-    FeK256 z = res[j].z, one, zero; k256::set_one(one); k256::set_zero(zero);
-    const bool zr = k256::is_zero(z);
-    if (zr) z = one;
-    FeK256 zi, t, x, y;
-    k256::mul(zi, ai, pre[j]);
-    k256::mul(ai, ai, z);
-    k256::sqr(t, zi);
-    k256::mul(x, res[j].x, t);
-    k256::mul(t, t, zi);
-    k256::mul(y, res[j].y, t);
-    if (zr) { x = zero; y = zero; }
-    if (out_fmt == FMT_PROJECTIVE) {        // (x : y : 1), identity (0 : 1 : 0)
-      if (zr) y = one;
-      u32* o = out + i * 24;
-      CurveK256::fe_store(o, x); CurveK256::fe_store(o + 8, y);
-      CurveK256::fe_store(o + 16, zr ? zero : one);
-    } else {
-      u32* o = out + i * 16;
-      CurveK256::fe_store(o, x); CurveK256::fe_store(o + 8, y);
-      if (out_inf) out_inf[i] = zr ? 1 : 0;
-    }
-  }
+  jac::store_batch_affine<CurveK256>(res, pre, cnt, base, T, out, out_fmt, out_inf);
 }
 
 // Two-term linear combination k0*P0 + k1*P1 sharing the 128 doublings (LinearCombination::lincomb,
@@ -450,13 +434,19 @@ __global__ void __launch_bounds__(256) mul_gen_ref_kernel(const u32* scalars, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// ok[i] = 1 iff every one of the `terms` scalars of element i is below the group order (Scalar::from_repr)
 template <class C>
-__global__ void __launch_bounds__(256) validate_scalars_kernel(const u32* scalars, uint8_t* ok, size_t n) {
+__global__ void __launch_bounds__(256) validate_scalars_kernel(const u32* scalars, uint8_t* ok, size_t n, size_t terms) {
   ECGPU_GRID_STRIDE(i, n) {
     u32 k[C::NW], o[C::NW];
-    C::scalar_load(k, scalars + i * C::NW);
     C::order(o);
-    ok[i] = mp_geq<C::NW>(k, o) ? 0 : 1;
+    bool good = true;
+#pragma unroll 1
+    for (size_t t = 0; t < terms; t++) {
+      C::scalar_load(k, scalars + (i * terms + t) * C::NW);
+      good = good && !mp_geq<C::NW>(k, o);
+    }
+    ok[i] = good ? 1 : 0;
   }
 }
 template <class C>
@@ -533,14 +523,6 @@ __device__ __forceinline__ void synth_value(u32* limbs, u64 seed, u64 stream, u6
     limbs[NW - 2 - 2 * j] = (u32)w;
   }
 }
-template <int NW>
-__device__ __forceinline__ void reduce_once(u32* v, const u32* m) {
-  u32 t[NW];
-  const u32 bw = mp_sub<NW>(t, v, m);
-#pragma unroll
-  for (int i = 0; i < NW; i++) v[i] = bw ? v[i] : t[i];
-}
-
 template <class C>
 __global__ void __launch_bounds__(256) synth_scalars_kernel(u64 seed, u64 first, u32* out, size_t n) {
   ECGPU_GRID_STRIDE(i, n) {

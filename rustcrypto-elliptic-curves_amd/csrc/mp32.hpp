@@ -29,6 +29,13 @@
 #define ECGPU_ASM 0
 #endif
 
+// Hook at every read of a precomputed-table entry; empty in the product.  The test-only host build (tests/hosttwin)
+// defines it to record the entry index, which is how the tests show that the constant-time schedules touch the same
+// entries in the same order whatever the scalar is, and that the throughput schedules do not.
+#ifndef ECGPU_TABLE_TOUCH
+#define ECGPU_TABLE_TOUCH(idx) ((void)0)
+#endif
+
 namespace ecgpu {
 
 typedef uint32_t u32;

@@ -17,15 +17,31 @@ ECGPU_HD void table_build(PtK256* t, const PtK256& p) {
 #pragma unroll 1
   for (int j = 0; j < 7; j++) pt_add(t[j + 1], p, t[j]);
 }
-// LookupTable::select (mul.rs:92-127): per-lane indexed read instead of the constant-time scan
-// (lanes are independent; the data is public bulk input), then the conditional negation.
+// LookupTable::select (mul.rs:92-127), the reference's constant-time scan: all eight entries are read whatever the
+// digit is - the addresses touched and the instructions executed do not depend on it - and merged under an
+// arithmetic mask (v_bfi_b32), then the conditional negation under the sign mask.  (Lanes are independent, so no
+// ballot or shuffle is involved: the scan is per lane, the digit never leaves its registers.)
 ECGPU_HD void table_select(PtK256& r, const PtK256* t, int d) {
-  const int ad = d < 0 ? -d : d;
-  PtK256 e = t[ad ? ad - 1 : 0];
-  PtK256 id; pt_identity(id);
-  pt_select(e, ad == 0, id, e);
+  const u32 sgn = (u32)d >> 31;                              // xmask (mul.rs:95)
+  const u32 ad = ((u32)d ^ (0u - sgn)) + sgn;                // xabs = (x + xmask) ^ xmask, 0..8
+  PtK256 e; pt_identity(e);
+#pragma unroll 1
+  for (u32 j = 1; j <= 8; j++) {
+    const u32 diff = ad ^ j;
+    const u32 m = 0u - ((diff - 1u) >> 31);                  // all ones iff xabs == j (diff < 2^31)
+    const PtK256& c = t[j - 1];
+    ECGPU_TABLE_TOUCH(j - 1);
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+      e.x.v[w] = (e.x.v[w] & ~m) | (c.x.v[w] & m);
+      e.y.v[w] = (e.y.v[w] & ~m) | (c.y.v[w] & m);
+      e.z.v[w] = (e.z.v[w] & ~m) | (c.z.v[w] & m);
+    }
+  }
   FeK256 ny; neg(ny, e.y);
-  select(e.y, d < 0, ny, e.y);
+  const u32 nm = 0u - sgn;                                   // neg_mask (mul.rs:122-124)
+#pragma unroll
+  for (int w = 0; w < 8; w++) e.y.v[w] = (e.y.v[w] & ~nm) | (ny.v[w] & nm);
   r = e;
 }
 

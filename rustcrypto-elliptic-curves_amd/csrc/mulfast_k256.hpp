@@ -134,6 +134,7 @@ ECGPU_HD void add_digit(JacK256& acc, const TabSlotK256* tab, int d, bool lam, b
   const int ad = d < 0 ? -d : d;
   if (ad != 0) {
     const TabSlotK256* e = tab + (2 * (ad - 1) + (lam ? 1 : 0));
+    ECGPU_TABLE_TOUCH(2 * (ad - 1) + (lam ? 1 : 0));
     FeK256 x = e->x;
     FeK256 y = e->y;
     if (neg != (d < 0)) k256::neg(y, y);

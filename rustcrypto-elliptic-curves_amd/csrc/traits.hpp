@@ -135,6 +135,18 @@ struct CurveNist {
   static ECGPU_HD void gen_table_build(Pt* tab) { nist::pt_generator<P>(tab[0]); }
   static ECGPU_HD void mul_gen_ref(Pt& r, const u32* k, const Pt* gen_tab, Pt* tab) { nist::mul_ref<P>(r, gen_tab[0], k, tab); }
 };
+// point formats of the C ABI (ecgpu_point_format)
+enum { FMT_AFFINE = 0, FMT_PROJECTIVE = 1 };
+
+// v -= m if v >= m (Reduce<U256>::reduce, k256 scalar.rs:700-713)
+template <int NW>
+ECGPU_HD void reduce_once(u32* v, const u32* m) {
+  u32 t[NW];
+  const u32 bw = mp_sub<NW>(t, v, m);
+#pragma unroll
+  for (int i = 0; i < NW; i++) v[i] = bw ? v[i] : t[i];
+}
+
 using CurveP256 = CurveNist<P256Params>;
 using CurveP384 = CurveNist<P384Params>;
 

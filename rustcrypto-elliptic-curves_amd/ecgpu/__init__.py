@@ -27,6 +27,7 @@ HOST, DEVICE = 0, 1
 AFFINE, PROJECTIVE = 0, 1
 EXACT_REFERENCE = 1
 ECDSA_LOW_S = 2
+PUBLIC_SCALARS = 4
 K256, P256, P384 = 0, 1, 2
 CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384}
 FIELD_BYTES = {K256: 32, P256: 32, P384: 48}
@@ -72,6 +73,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.ecgpu_point_add_mixed_batch.argtypes = [vp, i, u8p, u8p, u8p, sz, i]
     lib.ecgpu_point_double_batch.argtypes = [vp, i, u8p, u8p, sz, i]
     lib.ecgpu_batch_normalize.argtypes = [vp, i, u8p, u8p, u8p, sz, i]
+    lib.ecgpu_point_eq_batch.argtypes = [vp, i, u8p, u8p, u8p, sz, i]
+    lib.ecgpu_mul_batch_checked.argtypes = [vp, i, u8p, u8p, i, u8p, i, u8p, u8p, sz, i, ctypes.c_uint]
+    lib.ecgpu_lincomb_batch_checked.argtypes = [vp, i, u8p, u8p, i, sz, u8p, i, u8p, u8p, sz, i, ctypes.c_uint]
     lib.ecgpu_mul_batch.argtypes = [vp, i, u8p, u8p, i, u8p, i, u8p, sz, i, ctypes.c_uint]
     lib.ecgpu_lincomb_batch.argtypes = [vp, i, u8p, u8p, i, sz, u8p, i, u8p, sz, i, ctypes.c_uint]
     lib.ecgpu_msm.argtypes = [vp, i, u8p, u8p, i, sz, u8p, i, i]
@@ -91,7 +95,10 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
                  "ecgpu_field_op_batch", "ecgpu_point_add_batch", "ecgpu_point_add_mixed_batch",
                  "ecgpu_point_double_batch", "ecgpu_batch_normalize", "ecgpu_mul_batch", "ecgpu_lincomb_batch",
                  "ecgpu_msm", "ecgpu_validate_scalars", "ecgpu_validate_points", "ecgpu_decompress_batch",
-                 "ecgpu_synth_scalars", "ecgpu_synth_points"):
+                 "ecgpu_synth_scalars", "ecgpu_synth_points", "ecgpu_point_eq_batch", "ecgpu_mul_batch_checked",
+                 "ecgpu_lincomb_batch_checked", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_sign_batch", "ecgpu_to_bytes_batch",
+                 "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch",
+                 "ecgpu_ecdsa_recover_batch", "ecgpu_map_to_curve_batch"):
         getattr(lib, name).restype = ctypes.c_int
     if path is None:
         _lib = lib
@@ -105,6 +112,7 @@ EXPORTED_SYMBOLS = (
     "ecgpu_lincomb_batch", "ecgpu_msm", "ecgpu_validate_scalars", "ecgpu_validate_points", "ecgpu_decompress_batch",
     "ecgpu_synth_scalars", "ecgpu_synth_points", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_sign_batch",
     "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch", "ecgpu_ecdsa_recover_batch", "ecgpu_map_to_curve_batch",
+    "ecgpu_point_eq_batch", "ecgpu_mul_batch_checked", "ecgpu_lincomb_batch_checked",
 )
 
 
@@ -242,19 +250,39 @@ class Curve:
         self.ctx.check(self.ctx.lib.ecgpu_batch_normalize(self.ctx.handle, self.id, _ptr(p)[0], _ptr(out)[0], _ptr(inf)[0], len(p), HOST))
         return out, inf
 
+    def point_eq(self, p_xyz, q_xyz) -> np.ndarray:
+        """ProjectivePoint == ProjectivePoint (ct_eq) per element -> uint8 flags"""
+        p, q = _as_host(p_xyz, 3 * self.nb), _as_host(q_xyz, 3 * self.nb)
+        if len(p) != len(q):
+            raise ValueError("point batches differ in length")
+        eq = np.zeros(len(p), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ecgpu_point_eq_batch(self.ctx.handle, self.id, _ptr(p)[0], _ptr(q)[0], _ptr(eq)[0], len(p), HOST))
+        return eq
+
     # --- Mul<Scalar>, MulByGenerator, LinearCombination -----------------------------------------
     def lincomb(self, scalars, points, terms: int = 1, point_format: int = AFFINE, out_format: int = AFFINE, flags: int = 0,
-                out=None, out_inf=None):
-        """out / out_inf: optional preallocated result arrays (e.g. Context.pinned_array) instead of fresh ones."""
+                out=None, out_inf=None, checked: bool = False):
+        """out / out_inf: optional preallocated result arrays (e.g. Context.pinned_array) instead of fresh ones.
+        checked=True also returns scalar_ok (Scalar::from_repr: 0 where a scalar of the element is >= n)."""
         s = _as_host(scalars, self.nb)
+        if terms < 1 or len(s) % terms:
+            raise ValueError("the number of scalars is not a multiple of `terms`")
         n = len(s) // terms
         pw = (3 if point_format == PROJECTIVE else 2) * self.nb
         ow = (3 if out_format == PROJECTIVE else 2) * self.nb
         p = _as_host(points, pw) if points is not None else None
+        if p is not None and len(p) != n * terms:
+            raise ValueError("scalars and points differ in count (%d scalars, %d points)" % (len(s), len(p)))
         out = _host_out(n, ow) if out is None else out
         inf = np.zeros(n, dtype=np.uint8) if out_inf is None else out_inf
-        if out.shape != (n, ow) or out.dtype != np.uint8 or inf.shape != (n,) or not out.flags.c_contiguous:
-            raise ValueError("out / out_inf have the wrong shape")
+        if (out.shape != (n, ow) or out.dtype != np.uint8 or not out.flags.c_contiguous
+                or inf.shape != (n,) or inf.dtype != np.uint8 or not inf.flags.c_contiguous):
+            raise ValueError("out / out_inf have the wrong shape, dtype or layout")
+        if checked:
+            ok = np.zeros(n, dtype=np.uint8)
+            self.ctx.check(self.ctx.lib.ecgpu_lincomb_batch_checked(self.ctx.handle, self.id, _ptr(s)[0], _ptr(p)[0], point_format, terms,
+                                                                    _ptr(out)[0], out_format, _ptr(inf)[0], _ptr(ok)[0], n, HOST, flags))
+            return (out, inf, ok) if out_format == AFFINE else (out, ok)
         self.ctx.check(self.ctx.lib.ecgpu_lincomb_batch(self.ctx.handle, self.id, _ptr(s)[0], _ptr(p)[0], point_format, terms,
                                                         _ptr(out)[0], out_format, _ptr(inf)[0], n, HOST, flags))
         return (out, inf) if out_format == AFFINE else out
@@ -267,12 +295,22 @@ class Curve:
 
     def diffie_hellman(self, secret_scalars, public_keys_xy) -> np.ndarray:
         """elliptic_curve::ecdh::diffie_hellman for a batch: SharedSecret = x((public * secret).to_affine())
-        (k256/src/ecdh.rs:41-45).  Inputs are what the reference's types guarantee: non-zero scalars, valid keys."""
-        out, _ = self.mul(secret_scalars, public_keys_xy)
+        (k256/src/ecdh.rs:41-45).  Inputs are what the reference's types guarantee: non-zero scalars, valid keys.
+        The scalars are secret: the multiplication runs on the constant-time reference schedule."""
+        out, _ = self.mul(secret_scalars, public_keys_xy, flags=EXACT_REFERENCE)
         return np.ascontiguousarray(out[:, :self.nb])
+
+    def _check_device(self, t, need_bytes: int, what: str):
+        """size check for torch tensors handed to the *_device methods (raw integer pointers cannot be checked)"""
+        if t is not None and hasattr(t, "numel") and t.numel() * t.element_size() < need_bytes:
+            raise ValueError("%s holds %d bytes, the call needs %d" % (what, t.numel() * t.element_size(), need_bytes))
 
     def mul_device(self, d_scalars, d_points, d_out, n: int, point_format: int = AFFINE, out_format: int = AFFINE,
                    d_out_inf=None, flags: int = 0):
+        self._check_device(d_scalars, n * self.nb, "d_scalars")
+        self._check_device(d_points, n * (3 if point_format == PROJECTIVE else 2) * self.nb, "d_points")
+        self._check_device(d_out, n * (3 if out_format == PROJECTIVE else 2) * self.nb, "d_out")
+        self._check_device(d_out_inf, n, "d_out_inf")
         self.ctx.check(self.ctx.lib.ecgpu_mul_batch(self.ctx.handle, self.id, _ptr(d_scalars)[0], _ptr(d_points)[0], point_format,
                                                     _ptr(d_out)[0], out_format, _ptr(d_out_inf)[0], n, DEVICE, flags))
 
@@ -280,11 +318,16 @@ class Curve:
         s = _as_host(scalars, self.nb)
         pw = (3 if point_format == PROJECTIVE else 2) * self.nb
         p = _as_host(points, pw)
+        if len(p) != len(s):
+            raise ValueError("scalars and points differ in count (%d scalars, %d points)" % (len(s), len(p)))
         out = _host_out(1, (3 if out_format == PROJECTIVE else 2) * self.nb)
         self.ctx.check(self.ctx.lib.ecgpu_msm(self.ctx.handle, self.id, _ptr(s)[0], _ptr(p)[0], point_format, len(s), _ptr(out)[0], out_format, HOST))
         return out[0]
 
     def msm_device(self, d_scalars, d_points, n: int, d_out, point_format: int = AFFINE, out_format: int = AFFINE):
+        self._check_device(d_scalars, n * self.nb, "d_scalars")
+        self._check_device(d_points, n * (3 if point_format == PROJECTIVE else 2) * self.nb, "d_points")
+        self._check_device(d_out, (3 if out_format == PROJECTIVE else 2) * self.nb, "d_out")
         self.ctx.check(self.ctx.lib.ecgpu_msm(self.ctx.handle, self.id, _ptr(d_scalars)[0], _ptr(d_points)[0], point_format, n,
                                               _ptr(d_out)[0], out_format, DEVICE))
 

@@ -2,6 +2,7 @@
 // Lets the CPU test-suite check the exact code that the HIP kernels instantiate against the
 // oracle in a container without a GPU.  Never linked into libecgpu.so.
 #include <string.h>
+#include "hosttwin_trace.hpp"
 #include "fe_k256.hpp"
 using namespace ecgpu;
 
@@ -36,4 +37,17 @@ int ht_k256_fe_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, int 
   }
   return 0;
 }
+}
+
+// ---- table-access trace (hosttwin_trace.hpp): every ECGPU_TABLE_TOUCH of this library lands here ---------------------
+#include <vector>
+static thread_local std::vector<int> g_trace;
+static thread_local bool g_trace_on = false;
+extern "C" void ht_trace_push(int idx) { if (g_trace_on) g_trace.push_back(idx); }
+extern "C" void ht_trace_start(void) { g_trace.clear(); g_trace_on = true; }
+// stops recording; copies up to cap entries and returns the number recorded
+extern "C" size_t ht_trace_stop(int* out, size_t cap) {
+  g_trace_on = false;
+  for (size_t i = 0; i < g_trace.size() && i < cap; i++) out[i] = g_trace[i];
+  return g_trace.size();
 }

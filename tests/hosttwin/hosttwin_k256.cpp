@@ -1,5 +1,6 @@
 // TEST-ONLY host build of the k256 point / scalar-multiplication templates.
 #include <string.h>
+#include "hosttwin_trace.hpp"
 #include <stdlib.h>
 #include "mul_k256.hpp"
 using namespace ecgpu;

@@ -1,6 +1,7 @@
 // TEST-ONLY host build of the NIST (primeorder) templates through the curve traits.
 #include <string.h>
 #include <stdlib.h>
+#include "hosttwin_trace.hpp"
 #include "traits.hpp"
 using namespace ecgpu;
 
@@ -93,4 +94,24 @@ static int jac_op(int op, const uint8_t* p, const uint8_t* q, uint8_t* out, int 
 extern "C" int ht_jac_op(int curve, int op, const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
   if (curve == 0) return jac_op<CurveK256>(op, p, q, out, n);
   return curve == 1 ? jac_op<CurveP256>(op, p, q, out, n) : jac_op<CurveP384>(op, p, q, out, n);
+}
+
+// ---- per-lane body of the P-256 / P-384 variable-base kernel (varbase_lane.hpp), walked as `lanes` lanes -----------------
+// The kernel gives lane tid the units tid, tid + T, ... in passes of BATCH; here T = lanes is small, so a few hundred
+// units exercise every slot count 1..BATCH, several passes, the shared table inversion and the batched output.
+#include "varbase_lane.hpp"
+template <class C>
+static int vb_walk(const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, size_t lanes) {
+  constexpr int BATCH = 8;
+  vb::LaneWs<C, BATCH>* ws = (vb::LaneWs<C, BATCH>*)malloc(sizeof(vb::LaneWs<C, BATCH>));
+  for (size_t tid = 0; tid < lanes; tid++)
+    for (size_t base = tid; base < n; base += lanes * BATCH)
+      vb::lane_pass<C, BATCH>((const u32*)scalars, (const u32*)points, pt_fmt, (u32*)out, out_fmt, out_inf, n, base, lanes, *ws);
+  free(ws);
+  return 0;
+}
+extern "C" int ht_vb_mul(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
+                         size_t lanes) {
+  return curve == 1 ? vb_walk<CurveP256>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes)
+                    : vb_walk<CurveP384>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
 }

@@ -91,3 +91,116 @@ def test_caller_stream_ordering():
     st.synchronize()
     assert bool(same)
     ctx.close()
+
+
+def test_stream_switch_orders_shared_scratch():
+    """ecgpu_set_stream mid-way: host-buffer calls share the context's staging slots, so the second call (new stream)
+    must be ordered after the first (old stream); results are those of calls on a single stream."""
+    import torch
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve("k256")
+    n = 1 << 17
+    s1, p1 = CO.synth_scalars(0, n, synth.SEED, 11), CO.synth_points(0, n, synth.SEED, 11)
+    s2, p2 = CO.synth_scalars(0, n, synth.SEED, 999), CO.synth_points(0, n, synth.SEED, 999)
+    ref1, ref2 = cv.mul(s1, p1)[0].copy(), cv.mul(s2, p2)[0].copy()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    d_s1, d_p1 = torch.from_numpy(s1).cuda(), torch.from_numpy(p1).cuda()
+    d_s2, d_p2 = torch.from_numpy(s2).cuda(), torch.from_numpy(p2).cuda()
+    d_o1 = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    d_o2 = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):                      # device calls share the per-lane table workspace across the switch
+        ctx.set_stream(a.cuda_stream)
+        cv.mul_device(d_s1, d_p1, d_o1, n)
+        ctx.set_stream(b.cuda_stream)
+        cv.mul_device(d_s2, d_p2, d_o2, n)
+    ctx.synchronize()
+    a.synchronize()
+    assert bytes(d_o1.cpu().numpy()) == bytes(ref1) and bytes(d_o2.cpu().numpy()) == bytes(ref2)
+    ctx.set_stream(0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1), ("p384", 2)])
+def test_point_eq_and_checked_scalars(cn, cid):
+    """ProjectivePoint == (ct_eq, k256 projective.rs:421-446 / primeorder projective.rs:191-198) and the *_checked
+    forms that report scalars >= n per element (Scalar::from_repr, k256 scalar.rs:365-368)."""
+    import ecgpu
+    from oracle import ecmodel as M
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cn)
+    n = 300
+    s = CO.synth_scalars(cid, n, synth.SEED, 5)
+    p = CO.synth_points(cid, n, synth.SEED, 5)
+    xyz = cv.mul(s, p, out_format=ecgpu.PROJECTIVE)                                   # (x : y : 1)
+    ref = cv.mul(s, p, out_format=ecgpu.PROJECTIVE, flags=ecgpu.EXACT_REFERENCE)      # the reference's own (X : Y : Z)
+    assert bytes(xyz) != bytes(ref)
+    eq = cv.point_eq(xyz, ref)
+    assert eq.all()
+    other = np.roll(ref, 1, axis=0)
+    assert not cv.point_eq(xyz, other).any()
+    ident = np.frombuffer(M.proj_bytes(c, M.IDENTITY), dtype=np.uint8)
+    mix = ref.copy()
+    mix[0] = ident
+    eq = cv.point_eq(np.stack([ident, ident, xyz[2]]), np.stack([ident, ref[1], ident]))
+    assert eq.tolist() == [1, 0, 0]
+    # scalars >= n: reduced once for the arithmetic, flagged by the checked form
+    big = s.copy()
+    big[7] = np.frombuffer(M.i2b(c, c.n), dtype=np.uint8)
+    big[8] = np.frombuffer((c.n + 12345).to_bytes(nb, "big"), dtype=np.uint8)
+    big[9] = 0xFF
+    out, inf, ok = cv.lincomb(big, p, checked=True)
+    want_ok = np.ones(n, dtype=np.uint8)
+    want_ok[7:10] = 0
+    assert (ok == want_ok).all() and (ok == cv.validate_scalars(big)).all()
+    red = big.copy()
+    red[7] = 0
+    red[8] = np.frombuffer((12345).to_bytes(nb, "big"), dtype=np.uint8)
+    red[9] = np.frombuffer(((1 << (8 * nb)) - 1 - c.n).to_bytes(nb, "big"), dtype=np.uint8)
+    o2, i2 = cv.mul(red, p)
+    assert bytes(out) == bytes(o2) and bytes(inf) == bytes(i2) and inf[7] == 1
+    # two terms per element: one bad scalar spoils its element only
+    o3, i3, ok3 = cv.lincomb(big, p, terms=2, checked=True)
+    assert ok3.tolist() == [0 if j in (3, 4) else 1 for j in range(n // 2)]
+    # argument validation in the binding (a short points array would otherwise be read past its end)
+    with pytest.raises(ValueError):
+        cv.mul(s, p[:-1])
+    with pytest.raises(ValueError):
+        cv.lincomb(s[:-1], p[:-1], terms=2)
+    with pytest.raises(ValueError):
+        cv.msm(s, p[:-3])
+    # the empty sum
+    if cid == 0:
+        assert bytes(cv.msm(s[:0], p[:0])) == bytes(2 * nb)
+        assert bytes(cv.msm(s[:0], p[:0], out_format=ecgpu.PROJECTIVE)) == M.proj_bytes(c, M.IDENTITY)
+    ctx.close()
+
+
+@pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1), ("p384", 2)])
+def test_signing_schedules_agree_and_ecdh(cn, cid):
+    """Signing defaults to the constant-time reference schedule for k G; ECGPU_PUBLIC_SCALARS opts into the throughput
+    schedule.  Same signatures.  ECDH (a secret-scalar multiplication) goes through the reference schedule too."""
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cn)
+    n = 3000
+    d = CO.synth_scalars(cid, n, synth.SEED, 21)
+    k = CO.synth_scalars(cid, n, synth.SEED + 1, 21)
+    z = CO.synth_scalars(cid, n, synth.SEED + 2, 21)
+    fl = cv.default_ecdsa_flags()
+    sig_ct, rec_ct, ok_ct = cv.ecdsa_sign(d, k, z, flags=fl)
+    sig_pub, rec_pub, ok_pub = cv.ecdsa_sign(d, k, z, flags=fl | ecgpu.PUBLIC_SCALARS)
+    assert ok_ct.all() and bytes(sig_ct) == bytes(sig_pub) and bytes(rec_ct) == bytes(rec_pub) and bytes(ok_ct) == bytes(ok_pub)
+    s2, r2, _ = CO.ecdsa_sign_batch(cid, d[:200], k[:200], z[:200], low_s=(cid == 0))
+    assert bytes(sig_ct[:200]) == bytes(s2) and bytes(rec_ct[:200]) == bytes(r2)
+    q, _ = cv.mul_by_generator(d)
+    shared = cv.diffie_hellman(k, q)                 # k (dG)
+    q2, _ = cv.mul_by_generator(k)
+    shared2 = cv.diffie_hellman(d, q2)               # d (kG)
+    assert bytes(shared) == bytes(shared2)
+    want = CO.lincomb_batch(cid, k[:100], q[:100], threads=4)
+    assert bytes(shared[:100]) == bytes(np.ascontiguousarray(want[:, :cv.nb]))
+    ctx.close()

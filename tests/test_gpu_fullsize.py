@@ -1,0 +1,112 @@
+"""BASELINE.json's full sizes through the code paths they really take (first and last 4 096
+units, a strided sample of >= 32 768, all against the C oracle on the same seeded inputs).
+
+The variable-base kernels launch at most 4 workgroups per CU (262 144 lanes on 256 CUs); below that many units every
+lane holds ONE result.  Only at the BASELINE sizes does a lane carry several results per pass (slots b > 0 of its
+table workspace, the shared table inversion over all of them, the batched output inversion) and come back for a
+second pass:
+    config 5  p384  2^22 units:  8 slots per lane, two passes
+    p256      2^21 + 2^19 units: 8 slots, then a ragged second pass of 2
+    config 2  k256  2^24 units:  32 results per lane per pass, two passes
+Edge inputs (zero scalar, identity point, scalar >= n) are planted in slots b > 0 and in the second pass.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import coracle as CO
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+THREADS = max(1, min(os.cpu_count() or 1, 16))
+
+
+def _sample_indices(n, lanes, per_pass):
+    head = np.arange(0, 4096)
+    tail = np.arange(n - 4096, n)
+    stride = np.arange(0, n, max(1, n // 32768))
+    # the first units of every slot of both passes (slot b of pass q starts at q * per_pass + b * lanes)
+    slots = np.concatenate([np.arange(s, min(s + 8, n)) for s in range(0, n, lanes)])
+    return np.unique(np.concatenate([head, tail, stride, slots]))
+
+
+def _run_varbase(cname, cid, n, first, edges):
+    import torch
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    cv = ctx.curve(cname)
+    nb = cv.nb
+    lanes = 4 * torch.cuda.get_device_properties(0).multi_processor_count * 256
+    d_s = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
+    d_p = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+    d_o = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+    d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_s, n, synth.SEED, first)
+    cv.synth_points_device(d_p, n, synth.SEED, first)
+    order = {0: synth.M.K256.n, 1: synth.M.P256.n, 2: synth.M.P384.n}[cid]
+    planted = []
+    for slot, pass_, lane, kind in edges(lanes):
+        i = pass_ * lanes * (32 if cid == 0 else 8) + slot * lanes + lane
+        if i >= n:
+            continue
+        if kind == "zero":
+            d_s[i] = 0
+        elif kind == "ident":
+            d_p[i] = 0
+        elif kind == "n-1":
+            d_s[i] = torch.from_numpy(np.frombuffer((order - 1).to_bytes(nb, "big"), dtype=np.uint8).copy()).cuda()
+        elif kind == "n+3":                      # reduced once, like Reduce<U256>::reduce
+            d_s[i] = torch.from_numpy(np.frombuffer((order + 3).to_bytes(nb, "big"), dtype=np.uint8).copy()).cuda()
+        planted.append((i, kind))
+    cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i)
+    ctx.synchronize()
+    idx = np.unique(np.concatenate([_sample_indices(n, lanes, lanes * (32 if cid == 0 else 8)), np.array([i for i, _ in planted], dtype=np.int64)]))
+    t_idx = torch.from_numpy(idx).cuda()
+    s = d_s[t_idx].cpu().numpy()
+    p = d_p[t_idx].cpu().numpy()
+    got = torch.cat([d_o[t_idx], d_i[t_idx, None]], dim=1).cpu().numpy()
+    sw = s.copy()
+    # the oracle takes canonical scalars: reduce the planted n + 3 by hand
+    for i, kind in planted:
+        if kind == "n+3":
+            sw[np.searchsorted(idx, i)] = np.frombuffer((3).to_bytes(nb, "big"), dtype=np.uint8)
+    want = CO.lincomb_batch(cid, sw, p, threads=THREADS)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "units %s differ from the oracle" % idx[bad[:8]].tolist()
+    pos = {i: np.searchsorted(idx, i) for i, _ in planted}
+    for i, kind in planted:
+        if kind in ("zero", "ident"):
+            assert got[pos[i], -1] == 1 and not got[pos[i], :-1].any(), (i, kind)
+        else:
+            assert got[pos[i], -1] == 0, (i, kind)
+    assert int(d_i.sum().item()) == sum(1 for _, k in planted if k in ("zero", "ident"))
+    ctx.close()
+    return len(idx)
+
+
+def _edges(lanes):
+    # (slot, pass, lane, kind)
+    return [(3, 0, 5, "zero"), (5, 0, 77, "ident"), (7, 0, lanes - 1, "n-1"), (1, 0, 64, "n+3"),
+            (6, 1, 77, "zero"), (2, 1, 12345, "ident"), (1, 1, 1, "n-1"), (0, 1, 0, "n+3")]
+
+
+def test_p384_config5_2p22():
+    """BASELINE config 5 at its own size: vb::mul_kernel<CurveP384, 8, 4>, 8 slots per lane, two passes."""
+    assert _run_varbase("p384", 2, 1 << 22, 40_000_000, _edges) >= 32768 + 8192
+
+
+def test_p256_varbase_2p21_plus():
+    """p256 variable base with a full pass of 8 slots and a ragged second pass (2 slots, last one partial)."""
+    assert _run_varbase("p256", 1, (1 << 21) + (1 << 19) + 12345, 50_000_000, _edges) >= 32768 + 8192
+
+
+def test_k256_config2_2p24_second_pass():
+    """BASELINE config 2 at its own size: k256_mul_fast_kernel<32, 4>, 32 results per lane and pass, two passes
+    (kernels.hpp: base += T * BATCH)."""
+    def edges(lanes):
+        return [(3, 0, 5, "zero"), (17, 0, 77, "ident"), (31, 0, lanes - 1, "n-1"), (9, 0, 64, "n+3"),
+                (30, 1, 77, "zero"), (2, 1, 12345, "ident"), (31, 1, lanes - 1, "n-1"), (0, 1, 0, "n+3")]
+    assert _run_varbase("k256", 0, 1 << 24, 60_000_000, edges) >= 32768 + 8192
