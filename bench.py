@@ -3,26 +3,39 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE).  A "step" is one pass
-of the hot path over one batch: 2^24 independent (scalar, point) pairs per GPU (BASELINE.json
-configs[1]), inputs generated on the device from the synthetic-input spec (oracle/synth.py) and
-resident in HBM before the timed region.  Independent batches shard across GPUs with no
-data-path collective (weak scaling: per-GPU work is fixed); the only communication is the
-barrier and the max-over-ranks of the elapsed time.
+One process per GPU.  The driver launches N > 1 through torch.distributed.run (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment); called by hand with --gpus N > 1 and no WORLD_SIZE, this script
+starts that launcher itself as a child process (before anything touches the GPU) and relays its
+output and exit code.
+
+A "step" is one pass of the hot path over one batch: 2^24 independent (scalar, point) pairs per GPU
+(BASELINE.json configs[1]), inputs generated on the device from the synthetic-input spec
+(oracle/synth.py) and resident in HBM before the timed region.  Independent batches shard across
+GPUs with no data-path collective (weak scaling: per-GPU work is fixed); the split MSM
+(--workload k256_msm) all-gathers one projective point per rank and folds them on the device.
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
-  roofline     the dominant kernel against its bound.  This path is integer-VALU bound (no MFMA,
-               ~0.2 % of HBM): `bound` is "valu", achieved/peak are 32x32-bit multiply-accumulates
-               per second (v_mad_u64_u32 issue rate); the HBM view of the same kernel is under
-               roofline["hbm"] (algorithmic bytes, GB/s, fraction of 8 TB/s, PMC traffic if a
-               profiles/ summary is present).
-  cpu_baseline the C restatement of the reference CPU path (oracle/ecoracle.c, "port": rustc is not
-               available) timed on this box's host cores on a bounded sample of the same workload,
-               and used to check the GPU output of that sample byte for byte.
+  roofline      the dominant kernel against its bound.  This path is integer-VALU bound (no MFMA,
+                ~0.2 % of HBM): achieved/peak are 32x32-bit multiply-accumulates per second.
+                `peak` is the datasheet half-rate figure, `peak_measured` the v_mad_u64_u32 issue rate
+                measured on this GPU in this run (tools/ubench/peak.hip), `valu_busy_pct` and `traffic`
+                come from the committed rocprofv3 PMC summary (profiles/pmc_summary.json) of this
+                command; the HBM view of the same kernel is under roofline["hbm"].
+  cpu_baseline  the C restatement of the reference CPU path (oracle/ecoracle.c, "port": rustc is not
+                available) timed on this box's host cores on a bounded sample of the same workload
+                (median of 5, all cores and single thread), and used to check the GPU output of that
+                sample byte for byte.
+  other_configs (N = 1, default workload only) the other BASELINE.json configs - p256 fixed base 2^24,
+                k256 MSM 2^23 terms, p384 variable base 2^22 - run for a few steps each after the
+                headline, with their own parity checks, so that every config has a driver-run number.
+Every run checks parity: N = 1 against the CPU sample, N > 1 every rank's first and last 4 096 units
+against the oracle (MSM: the sum over ALL terms of all ranks against the closed form of structured
+points) - a mismatch anywhere makes the run exit non-zero.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,67 +45,114 @@ sys.path.insert(0, os.path.join(ROOT, "rustcrypto-elliptic-curves_amd"))
 
 SEED = 0xEC5CA1A5
 
-# ---- algorithmic work per unit (DESIGN.md section "Kernels and rooflines") ---------------------
-# unit = one k256 variable-base scalar multiplication with affine output.
-# 32x32-bit multiply-accumulates of the schoolbook products, 64 per 256-bit modular multiplication
-# or squaring; reduction and additions are not counted.
-MODMUL_PER_UNIT = {
-    # reference schedule: 128 doublings (6M+2S) + 80 additions (12M) + to_affine (255S + 17M)
-    "k256_varbase_ref": 128 * 8 + 80 * 12 + 272,
-    # throughput schedule (csrc/mulfast_k256.hpp): Jacobian, common-Z table, batched inversion (batch 32)
-    #   table   : 1 dbl (3M+4S) + 6 mixed adds (8M+3S) + rescale 7M + 7x(3M+1S) + 8 beta*x  =  87M + 29S
-    #   loop    : 128 dbl (3M+4S) + 66 mixed adds (8M+3S)                                   = 912M + 710S
-    #   output  : 2M (global Z) + batched normalise 6M+1S + (255S+15M)/32                   =   9M +   9S
-    "k256_varbase_fast": (87 + 912 + 9) + (29 + 710 + 9),
-}
-MAC_PER_MODMUL = 64
-BYTES_PER_UNIT = 32 + 64 + 65          # scalar + affine point in, x||y||inf out
+# ---- algorithmic work per unit ---------------------------------------------------------------
+# Work is counted in field multiplications (M) and squarings (S) per unit of the schedule that runs, with the EXPECTED
+# number of table additions (a signed 4-bit digit is zero with probability 1/16; the first addition into an empty
+# accumulator is a copy).  Two conversions to 32x32-bit multiply-accumulates:
+#   mac          SURVEY.md 8d convention: 64 (256-bit) or 144 (384-bit) per M or S - the schoolbook product only
+#   mac_issued   what the kernels really issue: k256 M = 64 + 8 fold products, S = 36 cross + 8 squares + 8 folds + 1;
+#                p256 M = S = 64 + 24 reduction terms; p384 M = 144 + 24, S = 66 + 12 + 48 (dedicated squaring)
+MAC_CONV = {"k256": 64, "p256": 64, "p384": 144}
+MAC_ISSUED = {"k256": (72, 53), "p256": (88, 88), "p384": (168, 126)}
 
-# Other BASELINE.json configs, selectable with --workload (the driver's default run is configs[1]).
-#   modmul: field multiplications/squarings per unit of the schedule that runs
-#   mac   : 32x32 multiply-accumulates of one schoolbook product (64 for 256-bit, 144 for 384-bit)
-WORKLOADS = {
-    "k256_varbase":   dict(curve="k256", cid=0, log2n=24, fixed=False, msm=False, metric="k256 variable-base scalar-muls/sec", unit="scalar-muls/s",
-                           modmul=None, mac=64, bytes_per_unit=32 + 64 + 65, kernel=None,
-                           desc="k256 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
-    "p256_fixedbase": dict(curve="p256", cid=1, log2n=24, fixed=True, msm=False, metric="p256 fixed-base (mul_by_generator) scalar-muls/sec", unit="scalar-muls/s",
-                           # batches >= 2^21: 13 signed 20-bit windows -> 13 mixed additions (8M+3S) + batched normalise 6M+1S + (256S+128M)/64
-                           modmul=13 * 11 + 7 + 6, mac=64, bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,20,64,4>",
-                           desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
-    "p384_varbase":   dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
-                           # 96 windows x (4 doublings (4M+4S) + 15/16 mixed additions (8M+3S)) + table (4 dbl + 3 add = 80) + its share of the
-                           # affine conversion (8 x 7 + 430 / 8) + output normalise 7 + 430 / 8
-                           modmul=96 * 32 + 90 * 11 + 80 + 110 + 61, mac=144, bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,4>",
-                           desc="p384 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
-    "k256_msm":       dict(curve="k256", cid=0, log2n=23, fixed=False, msm=True, metric="k256 MSM points/sec", unit="points/s",
-                           # 16 signed 16-bit windows: one mixed addition (8M+3S) per term per window; bucket reduction amortised
-                           modmul=16 * 11, mac=64, bytes_per_unit=32 + 64, kernel="msm::bucket_sum_kernel (+ digits/scan/scatter/reduce)",
-                           desc="k256 multi-scalar multiplication, 2^%d terms per GPU (one sum; ranks exchange one point each), affine output"),
-    # ECDSA verification: prep (scalar field) -> u1 G (16-bit fixed-base table) -> u2 Q (the headline
-    # kernel) -> inversion-free check.  Field modmuls: 1756 + 156 + 7; scalar-field work (27 dense Montgomery products of
-    # 136 MACs per signature) is folded in as 57 modmul equivalents.
-    "k256_ecdsa_verify": dict(curve="k256", cid=0, log2n=22, fixed=False, msm=False, ecdsa=True, metric="k256 ECDSA verifications/sec", unit="verifications/s",
-                           modmul=1756 + 156 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + k256_mul_fast_kernel<32,4> + verify_check",
-                           desc="k256 ECDSA verify_prehashed (low-s rule), 2^%d independent (prehash, signature, public key) triples per GPU"),
-    "p256_ecdsa_verify": dict(curve="p256", cid=1, log2n=22, fixed=False, msm=False, ecdsa=True, metric="p256 ECDSA verifications/sec", unit="verifications/s",
-                           modmul=3160 + 156 + 7 + 57, mac=64, bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + vb::mul_kernel<CurveP256,8,4> + verify_check",
-                           desc="p256 ECDSA verify_prehashed, 2^%d independent (prehash, signature, public key) triples per GPU"),
+WORK = {
+    # reference schedule: 128 doublings (6M+2S) + 80 complete additions (12M) + to_affine (255S + 17M)
+    "k256_varbase_ref": (128 * 6 + 80 * 12 + 17, 128 * 2 + 255),
+    # throughput schedule (csrc/mulfast_k256.hpp), batch of 32 results per inversion
+    #   table   : 1 dbl (3M+4S) + 6 mixed adds (8M+3S) + rescale 7M + 7x(3M+1S) + 8 beta*x            =  87M + 29S
+    #   loop    : 128 dbl (3M+4S) + 66 * 15/16 mixed adds (8M+3S)                                      = 879M + 697.6S
+    #   output  : 2M (global Z) + batched normalise 6M+1S + (255S+15M)/32                              =   9M +   9S
+    "k256_varbase_fast": (87 + 128 * 3 + 66 * 15 / 16 * 8 + 9, 29 + 128 * 4 + 66 * 15 / 16 * 3 + 9),
+    # 13 signed 20-bit windows: 12 mixed additions (the first is a copy) + normalise 6M+1S + (255S+12M)/64
+    "p256_fixedbase": (12 * 8 + 6 + 12 / 64, 12 * 3 + 1 + 255 / 64),
+    # 96 windows x 4 doublings (4M+4S) + 89 mixed additions (97 digits x 15/16, first one a copy) + table (4 dbl,
+    # 3 general additions 11M+5S) + table to affine 8 x (6M+1S) + (385S+14M)/8 + output normalise 6M+1S + (385S+14M)/8
+    "p384_varbase": (1536 + 89 * 8 + 49 + 48 + 14 / 8 + 6 + 14 / 8, 1536 + 89 * 3 + 31 + 8 + 385 / 8 + 1 + 385 / 8),
+    # bucket method, see msm_work() - filled from the schedule constants the library reports
+    "k256_msm": (16 * 8, 16 * 3),
+    # verification = u2 Q (headline kernel) + u1 G (20-bit table) + prep / check (57 scalar-field equivalents + 7)
+    "k256_ecdsa_verify": (87 + 128 * 3 + 66 * 15 / 16 * 8 + 9 + 12 * 8 + 6 + 64, 29 + 128 * 4 + 66 * 15 / 16 * 3 + 9 + 12 * 3 + 5),
+    "p256_ecdsa_verify": (64 * 4 * 4 + 61 * 11 + 49 + 6 + 12 * 8 + 6 + 64 + 700, 64 * 4 * 4 + 61 * 5 + 31 + 33 + 12 * 3 + 5),
 }
-# v_mad_u64_u32 issues at half the FP32-FMA rate on gfx950 (measured, tools/ubench/valu_rates.hip):
-# 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz
+
+WORKLOADS = {
+    "k256_varbase": dict(curve="k256", cid=0, log2n=24, fixed=False, msm=False, metric="k256 variable-base scalar-muls/sec", unit="scalar-muls/s",
+                         bytes_per_unit=32 + 64 + 65, kernel="k256_mul_fast_kernel<32,4>", pmc_match="k256_mul_fast_kernel",
+                         desc="k256 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
+    "p256_fixedbase": dict(curve="p256", cid=1, log2n=24, fixed=True, msm=False, metric="p256 fixed-base (mul_by_generator) scalar-muls/sec", unit="scalar-muls/s",
+                           bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,20,64,4>", pmc_match="mul_wide_kernel",
+                           desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
+    "p384_varbase": dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
+                         bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,4>", pmc_match="vb::mul_kernel",
+                         desc="p384 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
+    "k256_msm": dict(curve="k256", cid=0, log2n=23, fixed=False, msm=True, metric="k256 MSM points/sec", unit="points/s",
+                     bytes_per_unit=32 + 64, kernel="msm pipeline (digits / sort / bucket sums / reduce)", pmc_match="msm::",
+                     desc="k256 multi-scalar multiplication, 2^%d terms per GPU (one sum; ranks exchange one point each), affine output"),
+    "k256_ecdsa_verify": dict(curve="k256", cid=0, log2n=22, fixed=False, msm=False, ecdsa=True, metric="k256 ECDSA verifications/sec", unit="verifications/s",
+                              bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + k256_mul_fast_kernel<32,4> + verify_check", pmc_match="k256_mul_fast_kernel",
+                              desc="k256 ECDSA verify_prehashed (low-s rule), 2^%d independent (prehash, signature, public key) triples per GPU"),
+    "p256_ecdsa_verify": dict(curve="p256", cid=1, log2n=22, fixed=False, msm=False, ecdsa=True, metric="p256 ECDSA verifications/sec", unit="verifications/s",
+                              bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + vb::mul_kernel<CurveP256,8,4> + verify_check", pmc_match="vb::mul_kernel",
+                              desc="p256 ECDSA verify_prehashed, 2^%d independent (prehash, signature, public key) triples per GPU"),
+}
+OTHER_CONFIGS = ("p256_fixedbase", "k256_msm", "p384_varbase")      # BASELINE.json configs 3, 4 (one GPU's share), 5
+
+# v_mad_u64_u32 at half the FP32-FMA rate: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (datasheet-derived bound)
 PEAK_TMACS = 256 * 4 * 16 * 2.4e9 / 1e12
-# one exact multiply-accumulate is the pair v_mad_u64_u32 + v_addc_co_u32: 9.54 cycles per wave per SIMD at the
-# kernels' occupancy (profiles/r01_mac_mix_microbench.txt) -> the ceiling any column-accumulating schedule can reach
-MAC_PAIR_PEAK_TMACS = 256 * 4 * 64 * 2.4e9 / 9.54 / 1e12
 PEAK_HBM_GBS = 8000.0
 
-
 ECDSA_CORRUPT_EVERY = 7     # every 7th signature of the synthetic ECDSA batch has one bit of s flipped (must be rejected)
+CHECK_LEN = 4096            # N > 1: units at each end of a rank's slice compared with the oracle
+MSM_A0 = 0x1234567890ABCDEF1234567890ABCDEF0F1E2D3C4B5A6978          # structured MSM points P_i = (A0 + i * D) G
+MSM_D = 0xFEDCBA0987654321
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# structured MSM inputs: P_i = (a0 + i d) G, so sum k_i P_i = (sum k_i (a0 + i d) mod n) G
+# ---------------------------------------------------------------------------------------------------------------------
+def structured_point_scalars(first, n):
+    """(a0 + i d) for i in [first, first + n) as big-endian 32-byte rows; a0 < 2^192, d < 2^64, i < 2^40: no reduction needed."""
+    import numpy as np
+    i = np.arange(first, first + n, dtype=np.uint64)
+    d0, d1 = np.uint64(MSM_D & 0xFFFFFFFF), np.uint64(MSM_D >> 32)
+    ilo, ihi = i & np.uint64(0xFFFFFFFF), i >> np.uint64(32)
+    limbs = [None] * 8                      # little-endian 32-bit limbs as uint64 columns, carries propagated below
+    # i * d = (ilo + 2^32 ihi)(d0 + 2^32 d1)
+    t0 = ilo * d0
+    t1 = ilo * d1 + ihi * d0                # < 2^65 only if ihi large; i < 2^40 keeps ihi < 2^8, so no overflow
+    t2 = ihi * d1
+    acc = [t0 & np.uint64(0xFFFFFFFF), (t0 >> np.uint64(32)) + (t1 & np.uint64(0xFFFFFFFF)), (t1 >> np.uint64(32)) + (t2 & np.uint64(0xFFFFFFFF)), t2 >> np.uint64(32)]
+    acc += [np.zeros(n, dtype=np.uint64) for _ in range(4)]
+    carry = np.zeros(n, dtype=np.uint64)
+    for l in range(8):
+        v = acc[l] + np.uint64((MSM_A0 >> (32 * l)) & 0xFFFFFFFF) + carry
+        limbs[l] = (v & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        carry = v >> np.uint64(32)
+    be = np.stack([limbs[7 - j] for j in range(8)], axis=1).astype(">u4")
+    return np.ascontiguousarray(be).view(np.uint8).reshape(n, 32)
+
+
+def msm_expected_scalar(ks, first, order):
+    """sum_j k_j * (a0 + (first + j) d) mod order, from the big-endian scalar rows ks: two integer sums, no big-int loop."""
+    import numpy as np
+    n = ks.shape[0]
+    k16 = ks.view(">u2").reshape(n, 16)
+    j = np.arange(n, dtype=np.int64)
+    jl, jh = j & 0xFFF, j >> 12
+    s0 = s1 = 0
+    for col in range(16):
+        c = k16[:, col].astype(np.int64)
+        w = 16 * (15 - col)
+        s0 += int(c.sum()) << w
+        s1 += (int(np.dot(jl, c)) + (int(np.dot(jh, c)) << 12)) << w
+    return ((MSM_A0 + first * MSM_D) * s0 + MSM_D * s1) % order
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (forked children, BEFORE the parent touches the GPU)
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_ecdsa_worker(args):
-    """ECDSA workload in a forked child: inputs made with the C oracle (untimed), verification timed."""
-    first, n, cid = args
+    first, n, cid, reps = args
     import numpy as np
     from oracle import coracle as CO
     d = CO.synth_scalars(cid, n, SEED, first)
@@ -103,62 +163,356 @@ def cpu_ecdsa_worker(args):
     q = CO.lincomb_batch(cid, d, None, threads=1)[:, :-1].copy()
     idx = np.arange(first, first + n)
     sig[idx % ECDSA_CORRUPT_EVERY == 0, -1] ^= 1
-    t0 = time.perf_counter()
-    v = CO.ecdsa_verify_batch(cid, z, sig, q, low_s=low_s)
-    dt = time.perf_counter() - t0
-    return first, n, dt, sig.tobytes() + v.tobytes()
+    times, v = [], None
+    per = max(1, n // reps)
+    for r in range(reps):
+        lo, hi = r * per, (n if r == reps - 1 else (r + 1) * per)
+        t0 = time.perf_counter()
+        part = CO.ecdsa_verify_batch(cid, z[lo:hi], sig[lo:hi], q[lo:hi], low_s=low_s)
+        times.append((time.perf_counter() - t0, hi - lo))
+        v = part if v is None else np.concatenate([v, part])
+    return first, n, times, sig.tobytes() + v.tobytes()
 
 
 def cpu_baseline_worker(args):
-    """Runs in a forked child BEFORE the parent touches the GPU: C oracle on a slice."""
-    first, n, cid, fixed, msm = args
-    if msm == "ecdsa":
-        return cpu_ecdsa_worker((first, n, cid))
+    """C oracle on a slice, timed in `reps` equal chunks (the median chunk rate is what gets reported)."""
+    first, n, cid, fixed, kind, reps = args
+    if kind == "ecdsa":
+        return cpu_ecdsa_worker((first, n, cid, reps))
+    import numpy as np
     from oracle import coracle as CO
     s = CO.synth_scalars(cid, n, SEED, first)
-    p = None if fixed else CO.synth_points(cid, n, SEED, first)
-    t0 = time.perf_counter()
-    if msm:
-        # the reference has no Pippenger: its large-N form is one reference multiplication per term plus an addition
-        out = CO.lincomb_batch(cid, s, p, out_proj=True, threads=1)
+    if fixed:
+        p = None
+    elif kind == "msm":
+        p = CO.lincomb_batch(cid, structured_point_scalars(first, n), None, threads=1)[:, :-1].copy()     # untimed: P_i = (a0 + i d) G
     else:
-        out = CO.lincomb_batch(cid, s, p, threads=1)
-    dt = time.perf_counter() - t0
-    return first, n, dt, out.tobytes()
+        p = CO.synth_points(cid, n, SEED, first)
+    times, out = [], None
+    per = max(1, n // reps)
+    for r in range(reps):
+        lo, hi = r * per, (n if r == reps - 1 else (r + 1) * per)
+        if lo >= hi:
+            continue
+        t0 = time.perf_counter()
+        # MSM: the reference has no bucket method; its large-N form is one reference multiplication per term plus an addition
+        part = CO.lincomb_batch(cid, s[lo:hi], None if p is None else p[lo:hi], out_proj=(kind == "msm"), threads=1)
+        times.append((time.perf_counter() - t0, hi - lo))
+        out = part if out is None else np.concatenate([out, part])
+    return first, n, times, out.tobytes()
 
 
 SPREAD_BLOCKS, SPREAD_LEN = 16, 4096     # extra parity blocks spread over the batch (SURVEY.md 8d: sampled indices + the tail)
 
 
 def spread_blocks(n, sample):
-    """Start indices of the extra checked blocks: evenly spaced behind the timed sample, the last one ending the batch."""
     if n <= sample + SPREAD_BLOCKS * SPREAD_LEN:
         return []
     span = n - sample - SPREAD_LEN
     return [sample + (span * j) // (SPREAD_BLOCKS - 1) for j in range(SPREAD_BLOCKS)]
 
 
-def run_cpu_baseline(sample, procs, cid=0, fixed=False, msm=False, n=0):
-    """Reference CPU path (C port) on `sample` units spread over `procs` single-threaded processes; for the
-    element-wise workloads also SPREAD_BLOCKS blocks of SPREAD_LEN units across the rest of the batch (checked, not
-    part of the timed sample)."""
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def run_cpu_baseline(sample, procs, cid, fixed, kind, n, reps=5, single=True):
+    """Reference CPU path (C port) on `sample` units: all cores (one single-threaded process per core, each slice timed
+    in `reps` chunks; per chunk index the rate is units / slowest worker; median over the chunks) and one thread alone
+    (median of `reps` runs on a smaller slice).  For the element-wise workloads also SPREAD_BLOCKS blocks across the rest
+    of the batch, checked but not timed."""
     from concurrent.futures import ProcessPoolExecutor
     per = (sample + procs - 1) // procs
-    jobs = [(i * per, min(per, sample - i * per), cid, fixed, msm) for i in range(procs) if i * per < sample]
-    extra = [] if msm else [(st, SPREAD_LEN, cid, fixed, msm) for st in spread_blocks(n, sample)]
+    jobs = [(i * per, min(per, sample - i * per), cid, fixed, kind, reps) for i in range(procs) if i * per < sample]
+    extra = [] if kind in ("msm", "ecdsa") else [(st, SPREAD_LEN, cid, fixed, kind, 1) for st in spread_blocks(n, sample)]
+    extra_res = []
     if extra:
         with ProcessPoolExecutor(max_workers=procs) as ex:
             extra_res = [(r[0], r[1], r[3]) for r in ex.map(cpu_baseline_worker, extra)]
-    else:
-        extra_res = []
     t0 = time.perf_counter()
     with ProcessPoolExecutor(max_workers=procs) as ex:
         res = list(ex.map(cpu_baseline_worker, jobs))
     wall = time.perf_counter() - t0
-    busy = max(r[2] for r in res)      # slowest worker, excludes process start-up and input synthesis
-    outs = b"".join(r[3] for r in sorted(res))
-    return {"wall_s": wall, "busy_s": busy, "out": outs, "procs": len(jobs), "parts": [(r[0], r[1], r[3]) for r in sorted(res)],
-            "extra": extra_res}
+    nchunks = min(len(r[2]) for r in res)
+    rates = []
+    for ci in range(nchunks):
+        units = sum(r[2][ci][1] for r in res)
+        rates.append(units / max(r[2][ci][0] for r in res))
+    single_rate = None
+    if single:
+        sn = max(256, min(per, 4096 if cid == 0 else 1024 if cid == 1 else 512))
+        with ProcessPoolExecutor(max_workers=1) as ex:
+            r1 = list(ex.map(cpu_baseline_worker, [(0, sn, cid, fixed, kind, reps)]))[0]
+        single_rate = median([u / t for t, u in r1[2]])
+    return {"wall_s": wall, "rate": median(rates), "rates": rates, "single_rate": single_rate, "out": b"".join(r[3] for r in sorted(res)), "procs": len(jobs),
+            "parts": [(r[0], r[1], r[3]) for r in sorted(res)], "extra": extra_res, "reps": reps}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def maybe_launch_ranks(args):
+    """--gpus N > 1 without a launcher: become the parent of `python -m torch.distributed.run ... bench.py ...`.
+    Runs before torch / ecgpu are imported, so this process never initialises the GPU (an exec after that is forbidden)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def load_peak_lib():
+    import ctypes
+    path = os.path.join(ROOT, "tools", "ubench", "libecpeak.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.ecpeak_measure.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    return lib
+
+
+def measure_peak(device):
+    """(mad-only TMAC/s, mad+addc TMAC/s) measured now on this GPU, or (None, None) when the tool library is not built."""
+    import ctypes
+    lib = load_peak_lib()
+    if lib is None:
+        return None, None
+    a, b = ctypes.c_double(), ctypes.c_double()
+    if lib.ecpeak_measure(device, ctypes.byref(a), ctypes.byref(b)) != 0:
+        return None, None
+    return a.value, b.value
+
+
+def pmc_summary(match, log2n, default_size):
+    """Counters of the committed rocprofv3 PMC passes for this kernel (profiles/pmc_summary*.json), at the config's own size only."""
+    if log2n != default_size:
+        return {}
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_summary*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                js = json.load(f)
+        except Exception:
+            continue
+        for ent in (js if isinstance(js, list) else [js]):
+            if ent.get("kernel_match") and ent["kernel_match"] in match:
+                return ent
+    return {}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_workload(env, name, log2n, steps, warmup, schedule, cpu):
+    """Generate inputs on the device, time `steps` passes, check parity.  env: torch, ecgpu, ctx, dev, rank, world, dist, backend."""
+    import numpy as np
+    torch, ecgpu, ctx, dev = env["torch"], env["ecgpu"], env["ctx"], env["dev"]
+    rank, world, dist, backend = env["rank"], env["world"], env["dist"], env["backend"]
+    from oracle import coracle as CO
+    from oracle import ecmodel as M
+    wl = WORKLOADS[name]
+    n = 1 << log2n
+    cv = ctx.curve(wl["curve"])
+    nb = cv.nb
+    first = rank * n                         # disjoint slices of one global batch
+    d_s = torch.empty((n, nb), dtype=torch.uint8, device=dev)
+    d_p = None if wl["fixed"] else torch.empty((n, 2 * nb), dtype=torch.uint8, device=dev)
+    d_o = torch.empty((1 if wl["msm"] else n, 2 * nb), dtype=torch.uint8, device=dev)
+    d_i = torch.empty((n,), dtype=torch.uint8, device=dev)
+    cv.synth_scalars_device(d_s, n, SEED, first)
+    if wl["msm"]:
+        # structured points P_i = (a0 + i d) G, made on the device by the fixed-base kernel (untimed)
+        d_v = torch.from_numpy(structured_point_scalars(first, n)).to(dev)
+        cv.mul_device(d_v, None, d_p, n)
+        ctx.synchronize()
+        del d_v
+    elif d_p is not None:
+        cv.synth_points_device(d_p, n, SEED, first)
+    if wl.get("ecdsa"):
+        # d_s = secret keys; nonces and prehashes from two more seeded streams; public keys and signatures are made on
+        # the device (fixed-base kernel, sign pipeline) before the timed region; d_p holds the public keys
+        d_k = torch.empty((n, nb), dtype=torch.uint8, device=dev)
+        d_z = torch.empty((n, nb), dtype=torch.uint8, device=dev)
+        d_sig = torch.empty((n, 2 * nb), dtype=torch.uint8, device=dev)
+        cv.synth_scalars_device(d_k, n, SEED + 1, first)
+        cv.synth_scalars_device(d_z, n, SEED + 2, first)
+        cv.mul_device(d_s, None, d_p, n)
+        cv.ecdsa_sign_device(d_s, d_k, d_z, d_sig, None, d_i, n, flags=cv.default_ecdsa_flags() | ecgpu.PUBLIC_SCALARS)
+        ctx.synchronize()
+        bad = (torch.arange(first, first + n, device=dev) % ECDSA_CORRUPT_EVERY) == 0
+        d_sig[bad, -1] ^= 1
+    torch.cuda.synchronize()
+    d_part = torch.empty((3 * nb,), dtype=torch.uint8, device=dev)
+    d_all = torch.empty((max(world, 1), 3 * nb), dtype=torch.uint8, device=dev)
+    d_ones = torch.zeros((max(world, 1), nb), dtype=torch.uint8, device=dev)
+    d_ones[:, nb - 1] = 1
+    torch.cuda.synchronize()
+
+    def step():
+        if wl.get("ecdsa"):
+            cv.ecdsa_verify_device(d_z, d_sig, d_p, d_i, n)
+        elif wl["msm"]:
+            if dist is None:
+                cv.msm_device(d_s, d_p, n, d_o)
+            else:
+                # every rank sums its slice; one projective point per rank is all-gathered (96 bytes each; elliptic-curve
+                # addition is not an RCCL reduction operator) and the world's points are folded on the device
+                cv.msm_device(d_s, d_p, n, d_part, out_format=ecgpu.PROJECTIVE)
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(d_all, d_part)
+                else:                                    # gloo rehearsal on one card: the collective runs on host tensors
+                    ctx.synchronize()
+                    h = d_part.cpu()
+                    parts = [torch.empty_like(h) for _ in range(world)]
+                    dist.all_gather(parts, h)
+                    d_all.copy_(torch.stack(parts).to(dev))
+                    torch.cuda.synchronize()
+                cv.msm_device(d_ones, d_all, world, d_o, point_format=ecgpu.PROJECTIVE)
+        else:
+            cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i, flags=(ecgpu.EXACT_REFERENCE if schedule == "ref" else 0))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()                        # HIP events on the launch stream bracket the same region
+    for _ in range(steps):
+        step()
+    kernel_ms = ctx.timer_stop()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=(dev if backend == "nccl" else "cpu"))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- parity ---------------------------------------------------------------------------------------------------------
+    parity, checked = True, []
+    threads = max(1, min(8, (os.cpu_count() or 1) // max(1, min(world, 8))))
+    if wl["msm"]:
+        # the sum over ALL terms of all ranks against the closed form (O(N) scalar-field arithmetic on the host)
+        ks = CO.synth_scalars(0, n, SEED, first)
+        t_local = msm_expected_scalar(ks, first, M.K256.n)
+        del ks
+        if dist is not None:
+            objs = [None] * world
+            dist.all_gather_object(objs, t_local)
+            t_total = sum(objs) % M.K256.n
+        else:
+            t_total = t_local
+        want = M.affine_mul(M.K256, t_total, (M.K256.gx, M.K256.gy))
+        got = bytes(d_o.cpu().numpy().reshape(-1))
+        parity &= (got == (bytes(64) if want is None else M.i2b(M.K256, want[0]) + M.i2b(M.K256, want[1])))
+        checked.append("sum over all %d terms equals (sum k_i (a0 + i d) mod n) G for the structured points P_i = (a0 + i d) G" % (world * n))
+        if cpu is not None:
+            # and the first m terms against the oracle's term-by-term products folded with its complete addition
+            m = cpu["sample"]
+            parts = np.frombuffer(cpu["out"], dtype=np.uint8).reshape(m, 3 * nb)
+            ident = np.frombuffer(b"".join([bytes(nb), (1).to_bytes(nb, "big"), bytes(nb)]), dtype=np.uint8)[None, :]
+            while parts.shape[0] > 1:
+                if parts.shape[0] % 2:
+                    parts = np.concatenate([parts, ident])
+                parts = CO.point_op(wl["cid"], 0, parts[0::2].copy(), parts[1::2].copy())
+            d_chk = torch.empty((3 * nb,), dtype=torch.uint8, device=dev)
+            cv.msm_device(d_s, d_p, m, d_chk, out_format=ecgpu.PROJECTIVE)
+            ctx.synchronize()
+            g = d_chk.cpu().numpy().reshape(1, -1)
+
+            def aff(b):
+                X, Y, Z = (int.from_bytes(bytes(b[0][nb * t:nb * (t + 1)]), "big") for t in range(3))
+                return M.to_affine(M.K256, (X, Y, Z))
+
+            parity &= (aff(parts) == aff(g))
+            checked.append("first %d terms against the C oracle" % m)
+    elif wl.get("ecdsa"):
+        g_ok = d_i.cpu().numpy()
+        want_ok = (np.arange(first, first + n) % ECDSA_CORRUPT_EVERY != 0)
+        parity &= bool((g_ok.astype(bool) == want_ok).all())
+        checked.append("accept / reject flags of all units (every %dth signature corrupted)" % ECDSA_CORRUPT_EVERY)
+        if cpu is not None:
+            m = cpu["sample"]
+            g_sig = d_sig[:m].cpu().numpy()
+            for lo, cnt, blob in cpu["parts"]:
+                parity &= (g_sig[lo:lo + cnt].tobytes() == blob[:cnt * 2 * nb]) and (g_ok[lo:lo + cnt].tobytes() == blob[cnt * 2 * nb:])
+            checked.append("signatures and flags of the first %d units against the C oracle" % m)
+    else:
+        def rows(lo, cnt):
+            return torch.cat([d_o[lo:lo + cnt], d_i[lo:lo + cnt, None]], dim=1).cpu().numpy().tobytes()
+        if cpu is not None:
+            m = cpu["sample"]
+            parity &= (rows(0, m) == cpu["out"])
+            for lo, cnt, blob in cpu["extra"]:       # blocks spread over the rest of the batch, the last one at its end
+                parity &= (rows(lo, cnt) == blob)
+            checked.append("first %d units and %d blocks of %d spread to the end of the batch against the C oracle" % (m, len(cpu["extra"]), SPREAD_LEN))
+        else:
+            cl = min(CHECK_LEN if wl["curve"] != "p384" else CHECK_LEN // 4, n // 2)
+            for lo in (0, n - cl):
+                s = d_s[lo:lo + cl].cpu().numpy()
+                p = None if d_p is None else d_p[lo:lo + cl].cpu().numpy()
+                parity &= (rows(lo, cl) == CO.lincomb_batch(wl["cid"], s, p, threads=threads).tobytes())
+            checked.append("first and last %d units of every rank's slice against the C oracle" % cl)
+    if dist is not None:
+        t = torch.tensor([1 if parity else 0], dtype=torch.int32, device=(dev if backend == "nccl" else "cpu"))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        parity = bool(t.item())
+    del d_s, d_p, d_o, d_i
+    torch.cuda.empty_cache()
+    return {"name": name, "n": n, "log2n": log2n, "elapsed": elapsed, "kernel_ms": kernel_ms / steps, "steps": steps, "parity": bool(parity), "checked": checked,
+            "value": world * n * steps / elapsed}
+
+
+def roofline_for(name, res, schedule, peak_meas, pair_meas):
+    wl = WORKLOADS[name]
+    key = name if name != "k256_varbase" else "k256_varbase_" + schedule
+    m_cnt, s_cnt = WORK[key]
+    modmul = m_cnt + s_cnt
+    mac_conv = modmul * MAC_CONV[wl["curve"]]
+    iss_m, iss_s = MAC_ISSUED[wl["curve"]]
+    mac_issued = m_cnt * iss_m + s_cnt * iss_s
+    kernel_s = res["kernel_ms"] / 1e3
+    n = res["n"]
+    achieved = n * mac_conv / kernel_s / 1e12
+    issued = n * mac_issued / kernel_s / 1e12
+    pmc = pmc_summary(wl["pmc_match"], res["log2n"], wl["log2n"]) if schedule == "fast" else {}
+    ctr = pmc.get("counters_per_launch", {})
+    valu_busy = None
+    if "SQ_ACTIVE_INST_VALU" in ctr and "GRBM_GUI_ACTIVE" in ctr:
+        # gfx94x formula of the derived metric (the guide: gfx950 falls back to it): busy VALU cycles over SIMD cycles;
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_ACTIVE_INST_VALU counts quad-cycles over all 1024 SIMDs
+        valu_busy = 100.0 * ctr["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (ctr["GRBM_GUI_ACTIVE"] / 8)
+    if "VALUBusy" in ctr:
+        valu_busy = ctr["VALUBusy"]
+    alg_bytes = n * wl["bytes_per_unit"]
+    r = {
+        "bound": "valu", "achieved": achieved, "peak": PEAK_TMACS, "unit": "TMAC/s (32x32+64 v_mad_u64_u32)", "frac": achieved / PEAK_TMACS,
+        "traffic": pmc.get("hbm_bytes_per_launch"),
+        "kernel": ("lincomb_ref_kernel<CurveK256,1>" if (name == "k256_varbase" and schedule == "ref") else wl["kernel"]), "kernel_ms": res["kernel_ms"],
+        "modmul_per_unit": round(modmul, 1), "mac_per_unit": round(mac_conv), "mac_issued_per_unit": round(mac_issued),
+        "achieved_issued": issued, "frac_issued": issued / PEAK_TMACS,
+        "peak_measured": peak_meas, "frac_of_peak_measured": (achieved / peak_meas if peak_meas else None),
+        "mac_pair_peak_measured": pair_meas, "frac_of_mac_pair_peak": (issued / pair_meas if pair_meas else None),
+        "valu_busy_pct": valu_busy,
+        "valu_insts_per_launch": ctr.get("SQ_INSTS_VALU"),
+        "hbm": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": alg_bytes / kernel_s / 1e9 / PEAK_HBM_GBS, "bytes_per_unit": wl["bytes_per_unit"]},
+    }
+    return r
+
+
+def cpu_plan(wl, n, cpu_sample, procs):
+    per_proc = {"k256": 61440, "p256": 7680, "p384": 3840}[wl["curve"]]
+    if wl.get("ecdsa"):
+        per_proc //= 2                  # a verification is two scalar multiplications on the CPU
+    return cpu_sample or min(n, per_proc * procs)
 
 
 def main():
@@ -170,11 +524,14 @@ def main():
                     help="BASELINE.json config to run (default: configs[1], the headline metric)")
     ap.add_argument("--log2n", type=int, default=0, help="units per GPU per step (0 = the config's size)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="units for the CPU baseline (0 = auto, about 10-20 s)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="processes of the all-core CPU baseline (0 = all host cores, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs 3, 4, 5 after the headline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse several ranks on one GPU)")
     ap.add_argument("--schedule", choices=["fast", "ref"], default="fast",
                     help="fast = throughput schedule (affine result specified); ref = reference-faithful schedule (exact XYZ)")
     args = ap.parse_args()
+    maybe_launch_ranks(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -183,22 +540,23 @@ def main():
     if not args.log2n:
         args.log2n = wl["log2n"]
     n = 1 << args.log2n
+    others = list(OTHER_CONFIGS) if (world == 1 and args.workload == "k256_varbase" and args.schedule == "fast" and args.log2n == wl["log2n"]
+                                     and not args.no_other_configs) else []
 
     # ---- CPU baseline first (rank 0, N = 1 only), before this process initialises the GPU ----------
-    cpu = None
+    cpu, cpu_others = None, {}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        procs = max(1, min(os.cpu_count() or 1, 16))
-        # the C port runs ~16 k units/s/core: 64 k units per process is ~4 s of work each (about a minute of CPU
-        # time on 16 cores); --cpu-sample overrides
-        per_proc = {"k256": 65536, "p256": 8192, "p384": 4096}[wl["curve"]] // (1 if not wl["fixed"] or wl["curve"] != "k256" else 1)
-        sample = args.cpu_sample or min(n, per_proc * procs)
-        if wl.get("ecdsa"):
-            per_proc //= 2                  # a verification is two scalar multiplications on the CPU
-            sample = args.cpu_sample or min(n, per_proc * procs)
-        cpu = run_cpu_baseline(sample, procs, wl["cid"], wl["fixed"], "ecdsa" if wl.get("ecdsa") else wl["msm"], n)
+        procs = args.cpu_threads or max(1, min(os.cpu_count() or 1, 16))
+        kind = "ecdsa" if wl.get("ecdsa") else ("msm" if wl["msm"] else "mul")
+        sample = cpu_plan(wl, n, args.cpu_sample, procs)
+        cpu = run_cpu_baseline(sample, procs, wl["cid"], wl["fixed"], kind, n)
         cpu["sample"] = sample
+        for o in others:            # small untimed-grade samples: parity of the other configs (and a rough rate)
+            w2 = WORKLOADS[o]
+            s2 = min(1 << w2["log2n"], {"k256": 16384, "p256": 2048, "p384": 1024}[w2["curve"]] * procs)
+            cpu_others[o] = run_cpu_baseline(s2, procs, w2["cid"], w2["fixed"], "msm" if w2["msm"] else "mul", 1 << w2["log2n"], reps=1, single=False)
+            cpu_others[o]["sample"] = s2
 
-    import numpy as np
     import torch
     import ecgpu
 
@@ -218,175 +576,68 @@ def main():
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     ctx = ecgpu.Context(local_rank)
-    cv = ctx.curve(wl["curve"])
-    nb = cv.nb
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+    env = {"torch": torch, "ecgpu": ecgpu, "ctx": ctx, "dev": torch.device("cuda", local_rank), "rank": rank, "world": world, "dist": dist,
+           "backend": args.backend}
 
-    dev = torch.device("cuda", local_rank)
-    d_s = torch.empty((n, nb), dtype=torch.uint8, device=dev)
-    d_p = None if wl["fixed"] else torch.empty((n, 2 * nb), dtype=torch.uint8, device=dev)
-    d_o = torch.empty((1 if wl["msm"] else n, 2 * nb), dtype=torch.uint8, device=dev)
-    d_i = torch.empty((n,), dtype=torch.uint8, device=dev)
-    first = rank * n                         # disjoint slices of one global batch
-    cv.synth_scalars_device(d_s, n, SEED, first)
-    if d_p is not None:
-        cv.synth_points_device(d_p, n, SEED, first)
-    if wl.get("ecdsa"):
-        # d_s = secret keys; nonces and prehashes from two more seeded streams; public keys and signatures are made on
-        # the device (fixed-base kernel, sign pipeline) before the timed region; d_p holds the public keys
-        d_k = torch.empty((n, nb), dtype=torch.uint8, device=dev)
-        d_z = torch.empty((n, nb), dtype=torch.uint8, device=dev)
-        d_sig = torch.empty((n, 2 * nb), dtype=torch.uint8, device=dev)
-        cv.synth_scalars_device(d_k, n, SEED + 1, first)
-        cv.synth_scalars_device(d_z, n, SEED + 2, first)
-        cv.mul_device(d_s, None, d_p, n)
-        cv.ecdsa_sign_device(d_s, d_k, d_z, d_sig, None, d_i, n)
-        ctx.synchronize()
-        bad = (torch.arange(first, first + n, device=dev) % ECDSA_CORRUPT_EVERY) == 0
-        d_sig[bad, -1] ^= 1
-    torch.cuda.synchronize()
-    msm_result = {}
+    res = run_workload(env, args.workload, args.log2n, args.steps, args.warmup, args.schedule, cpu)
+    other_res = []
+    for o in others:
+        other_res.append(run_workload(env, o, WORKLOADS[o]["log2n"], max(2, min(args.steps, 5)), 1, "fast", cpu_others.get(o)))
+    peak_meas, pair_meas = measure_peak(local_rank) if rank == 0 else (None, None)
 
-    def step():
-        if wl.get("ecdsa"):
-            cv.ecdsa_verify_device(d_z, d_sig, d_p, d_i, n)
-        elif wl["msm"]:
-            if dist is None:
-                cv.msm_device(d_s, d_p, n, d_o)
-            else:
-                # every rank sums its slice; one projective point per rank is all-gathered and folded locally
-                from ecgpu import parallel
-                d_part = torch.empty((3 * nb,), dtype=torch.uint8, device=dev)
-
-                def local_msm(lo, hi):
-                    cv.msm_device(d_s, d_p, n, d_part, out_format=ecgpu.PROJECTIVE)
-                    ctx.synchronize()
-                    return d_part.cpu().numpy()
-
-                tot = parallel.msm_sharded(local_msm, lambda a, b: cv.add(a.reshape(1, -1), b.reshape(1, -1))[0], world * n)
-                msm_result["xyz"] = tot
-        else:
-            cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i, flags=(ecgpu.EXACT_REFERENCE if args.schedule == "ref" else 0))
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    ctx.timer_start()                        # HIP events on the launch stream bracket the same region
-    for _ in range(args.steps):
-        step()
-    kernel_ms = ctx.timer_stop()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- parity of the sample against the CPU oracle (same seeded inputs) ----------------------------
-    parity = None
-    if cpu is not None:
-        m = cpu["sample"]
-        if wl.get("ecdsa"):
-            # signatures made on the device and accept/reject flags, against the C oracle's for the same indices
-            g_sig, g_ok = d_sig[:m].cpu().numpy(), d_i[:m].cpu().numpy()
-            parity = True
-            for lo, cnt, blob in cpu["parts"]:
-                parity &= (g_sig[lo:lo + cnt].tobytes() == blob[:cnt * 2 * nb]) and (g_ok[lo:lo + cnt].tobytes() == blob[cnt * 2 * nb:])
-            want_ok = (np.arange(m) % ECDSA_CORRUPT_EVERY != 0)
-            parity &= bool((g_ok.astype(bool) == want_ok).all())
-        elif wl["msm"]:
-            # the oracle computed k_i * P_i for the first m terms (projective); fold them with the oracle's
-            # complete addition and compare with the GPU MSM over the same m terms
-            from oracle import coracle as CO
-            parts = np.frombuffer(cpu["out"], dtype=np.uint8).reshape(m, 3 * nb)
-            while parts.shape[0] > 1:
-                if parts.shape[0] % 2:
-                    parts = np.concatenate([parts, np.frombuffer(b"".join([bytes(nb), (1).to_bytes(nb, "big"), bytes(nb)]), dtype=np.uint8)[None, :]])
-                parts = CO.point_op(wl["cid"], 0, parts[0::2].copy(), parts[1::2].copy())
-            d_chk = torch.empty((3 * nb,), dtype=torch.uint8, device=dev)
-            cv.msm_device(d_s, d_p, m, d_chk, out_format=ecgpu.PROJECTIVE)
-            ctx.synchronize()
-            g = d_chk.cpu().numpy().reshape(1, -1)
-            # compare as group elements: normalise both through the library-independent route (x = X/Z)
-            from oracle import ecmodel as M
-            c_ = M.CURVES[wl["curve"]]
-
-            def aff(b):
-                X, Y, Z = (int.from_bytes(bytes(b[0][nb * t:nb * (t + 1)]), "big") for t in range(3))
-                return M.to_affine(c_, (X, Y, Z))
-
-            parity = aff(parts) == aff(g)
-        else:
-            got = torch.cat([d_o[:m], d_i[:m, None]], dim=1).cpu().numpy().tobytes()
-            parity = (got == cpu["out"])
-            for lo, cnt, blob in cpu["extra"]:       # blocks spread over the rest of the batch, the last one at its end
-                parity &= (torch.cat([d_o[lo:lo + cnt], d_i[lo:lo + cnt, None]], dim=1).cpu().numpy().tobytes() == blob)
-        if not parity:
-            raise SystemExit("PARITY FAILURE: GPU output differs from the CPU oracle on the sampled units")
-
+    ok = res["parity"] and all(r["parity"] for r in other_res)
     if rank == 0:
-        units = world * n * args.steps
-        value = units / elapsed
-        kernel_s = kernel_ms / 1e3 / args.steps            # average launch duration, HIP events
-        modmul = wl["modmul"] or MODMUL_PER_UNIT["k256_varbase_" + args.schedule]
-        macs_per_launch = n * modmul * wl["mac"]
-        achieved_tmacs = macs_per_launch / kernel_s / 1e12
-        alg_bytes = n * wl["bytes_per_unit"]
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc) and args.workload == "k256_varbase" and args.schedule == "fast" and args.log2n == 24:
-            try:
-                with open(pmc) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         line = {
             "metric": wl["metric"],
-            "value": value,
+            "value": res["value"],
             "unit": wl["unit"],
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": res["elapsed"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": wl["desc"] % args.log2n,
-                       "units_per_gpu_per_step": n, "parallelism": (("one sum split over %d GPU(s): per-rank Pippenger, all-gather of one projective point per rank, local complete additions" % world)
+                       "units_per_gpu_per_step": n,
+                       "parallelism": (("one sum split over %d GPU(s): per-rank bucket method, all-gather of one projective point per rank, fold on the device" % world)
                                        if wl["msm"] else ("independent batches, %d GPU(s), no collective" % world)),
-                       "schedule": ("reference-faithful (GLV + signed radix-16, RCB complete formulas, per-point inversion)" if args.schedule == "ref"
+                       "schedule": ("reference-faithful (GLV + signed radix-16, RCB complete formulas, constant-time table scans, per-point inversion)" if args.schedule == "ref"
                                     else "throughput (GLV + signed radix-16, Jacobian, common-Z table, batched inversion)")
                        if args.workload == "k256_varbase" else "throughput schedule of this workload (DESIGN.md section 4)"},
-            "roofline": {
-                "bound": "valu", "achieved": achieved_tmacs, "peak": PEAK_TMACS, "unit": "TMAC/s (32x32+64 v_mad_u64_u32)",
-                "frac": achieved_tmacs / PEAK_TMACS, "traffic": traffic,
-                "kernel": wl["kernel"] or ("lincomb_ref_kernel<CurveK256,1>" if args.schedule == "ref" else "k256_mul_fast_kernel<32,4>"), "kernel_ms": kernel_s * 1e3,
-                "modmul_per_unit": modmul, "mac_per_unit": modmul * wl["mac"],
-                "mac_pair_peak": MAC_PAIR_PEAK_TMACS, "frac_of_mac_pair_peak": achieved_tmacs / MAC_PAIR_PEAK_TMACS,
-                "hbm": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": alg_bytes / kernel_s / 1e9 / PEAK_HBM_GBS, "bytes_per_unit": BYTES_PER_UNIT},
-            },
+            "parity_ok": res["parity"],
+            "parity_checked": res["checked"],
+            "roofline": roofline_for(args.workload, res, args.schedule, peak_meas, pair_meas),
         }
         if cpu is not None:
             line["cpu_baseline"] = {
-                "value": cpu["sample"] / cpu["busy_s"], "unit": wl["unit"], "cores": cpu["procs"], "kind": "port",
-                "sample": "first %d units of the same seeded batch, C restatement of the reference path (oracle/ecoracle.c), %d single-threaded processes; GPU output of the sample%s verified byte-identical" % (
-                    cpu["sample"], cpu["procs"], (" and of %d more blocks of %d units spread to the end of the batch" % (len(cpu["extra"]), SPREAD_LEN)) if cpu.get("extra") else ""),
-                "wall_s": cpu["wall_s"], "parity_ok": bool(parity),
+                "value": cpu["rate"], "unit": wl["unit"], "cores": cpu["procs"], "kind": "port",
+                "sample": "first %d units of the same seeded batch, C restatement of the reference path (oracle/ecoracle.c), %d single-threaded processes, each slice timed in %d chunks: median chunk rate" % (
+                    cpu["sample"], cpu["procs"], cpu["reps"]),
+                "single_thread": {"value": cpu["single_rate"], "cores": 1, "median_of": cpu["reps"]},
+                "wall_s": cpu["wall_s"], "parity_ok": res["parity"],
             }
+        if other_res:
+            line["other_configs"] = []
+            for r in other_res:
+                w2 = WORKLOADS[r["name"]]
+                ent = {"metric": w2["metric"], "value": r["value"], "unit": w2["unit"], "config": w2["desc"] % r["log2n"], "steps": r["steps"],
+                       "ms_per_step": r["elapsed"] / r["steps"] * 1e3, "parity_ok": r["parity"], "parity_checked": r["checked"],
+                       "roofline": roofline_for(r["name"], r, "fast", peak_meas, pair_meas)}
+                c2 = cpu_others.get(r["name"])
+                if c2 is not None:
+                    ent["cpu_baseline"] = {"value": c2["rate"], "unit": w2["unit"], "cores": c2["procs"], "kind": "port", "sample": "first %d units, one pass" % c2["sample"]}
+                line["other_configs"].append(ent)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
     ctx.close()
+    if not ok:
+        raise SystemExit("PARITY FAILURE: GPU output differs from the CPU oracle / closed form (see parity_ok in the line above)")
 
 
 if __name__ == "__main__":

@@ -46,6 +46,7 @@ def _run_varbase(cname, cid, n, first, edges):
     d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
     cv.synth_scalars_device(d_s, n, synth.SEED, first)
     cv.synth_points_device(d_p, n, synth.SEED, first)
+    ctx.synchronize()          # torch's default stream has handle 0 = "the context's own stream": not ordered with torch's work
     order = {0: synth.M.K256.n, 1: synth.M.P256.n, 2: synth.M.P384.n}[cid]
     planted = []
     for slot, pass_, lane, kind in edges(lanes):
@@ -61,6 +62,7 @@ def _run_varbase(cname, cid, n, first, edges):
         elif kind == "n+3":                      # reduced once, like Reduce<U256>::reduce
             d_s[i] = torch.from_numpy(np.frombuffer((order + 3).to_bytes(nb, "big"), dtype=np.uint8).copy()).cuda()
         planted.append((i, kind))
+    torch.cuda.synchronize()
     cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i)
     ctx.synchronize()
     idx = np.unique(np.concatenate([_sample_indices(n, lanes, lanes * (32 if cid == 0 else 8)), np.array([i for i, _ in planted], dtype=np.int64)]))
