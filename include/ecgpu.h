@@ -20,7 +20,7 @@
  *      projective point       : X || Y || Z (3*NB), homogeneous (x = X/Z), identity (0, 1, 0)
  *                               (k256 projective.rs:38-50, primeorder projective.rs:37-52).
  *  - `mem` says where the caller's buffers live: ECGPU_MEM_HOST (the library stages them
- *    through HBM) or ECGPU_MEM_DEVICE (pointers into this GPU's HBM, 4-byte aligned; the
+ *    through HBM) or ECGPU_MEM_DEVICE (pointers into this GPU's HBM, 16-byte aligned; the
  *    call is asynchronous on the context's stream).
  *  - Every function returns 0 on success or a negative ecgpu_status; ecgpu_last_error() gives
  *    the text.  Arithmetic on valid inputs cannot fail.  Decoding failures (scalar >= n,

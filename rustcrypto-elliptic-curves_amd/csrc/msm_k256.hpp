@@ -3,9 +3,13 @@
 // The reference's form of this operation is lincomb_ext over a slice (k256/src/arithmetic/mul.rs:325-393),
 // a Straus interleaving with two 8-point tables per term - O(n) table memory and 128 shared
 // doublings, unusable at 2^20..2^26 terms.  The result is the same group element; the schedule here is
-//   1. signed c-bit digits of every scalar (c = 16: 16 windows + a carry window, 2^15 buckets per window)
-//   2. counting sort of the (term, window) pairs by bucket: LDS-privatised histogram, exclusive scan, scatter
-//   3. one lane per bucket sums its points with Jacobian mixed additions (exceptional cases handled)
+//   0. the GLV split of every scalar (decompose_scalar, mul.rs:260-268: k = k1 + k2 lambda, |k1|, |k2| < 2^128), so a term
+//      is two half-terms (k1, P) and (k2, lambda P = (beta x, y)) and there are 8 windows instead of 16: half the buckets
+//      to reduce and 128 instead of 256 doublings in the serial tail, for the same number of bucket additions
+//   1. signed c-bit digits of every half-scalar, computed once (c = 16: 8 windows + a carry window, 2^15 buckets per window)
+//   2. two-level counting sort of the (half-term, window) pairs by bucket (512 coarse bins, then 64 buckets within a
+//      bin; LDS-privatised counters at both levels, msm_kernels.hpp)
+//   3. one lane per bucket sums its points in XYZZ coordinates (mixed addition 8M + 2S; exceptional cases handled)
 //   4. per window sum_j j*B_j by segmented running sums, then Horner over the windows
 // Every stage is a kernel over device memory; no host round trips until the final point.
 #pragma once
@@ -15,9 +19,10 @@ namespace ecgpu {
 namespace msm {
 
 constexpr int C = 16;                         // window bits
-constexpr int NWIN = 17;                      // 16 full windows + the carry of the signed recoding
+constexpr int NHALF = 2;                      // GLV halves per term
+constexpr int NWIN = 9;                       // 8 full windows of a 128-bit half + the carry of the signed recoding
+constexpr int NDIG = NWIN * NHALF;            // digit columns per term
 constexpr int NBUCKET = 1 << (C - 1);         // |digit| in 1..2^15
-constexpr int SORT_CHUNKS = 15;               // workgroups per window in the counting sort: 17 x 15 = 255, one per CU
 // bucket reduction tree: 2^15 buckets = NSEG1 x SEG1 x SEG0 per window.  Short runs keep the dependent chains of the
 // two segment kernels short (16 and 32 additions); the window kernel finishes with LDS tree sums over NSEG1 lanes.
 constexpr int LOG_SEG0 = 3, SEG0 = 1 << LOG_SEG0;     // buckets per level-0 run
@@ -52,6 +57,54 @@ ECGPU_HD void jac_add(JacK256& r, const JacK256& p, const JacK256& q) {
   mul(s1, s1, hhh); sub(o.y, t, s1);
   mul(t, p.z, q.z); mul(o.z, t, h);
   r = o;
+}
+
+
+// XYZZ coordinates for the bucket accumulators: x = X / ZZ, y = Y / ZZZ with ZZ^3 = ZZZ^2, infinity <=> ZZ = 0.
+// Adding an affine point costs 8M + 2S (madd-2008-s), one squaring less than the Jacobian mixed addition; the 134 M
+// bucket additions of a 2^23-term sum are where that squaring counts.  Buckets leave the accumulation as Jacobian
+// triples (X ZZ, Y ZZZ, ZZ) - two multiplications - because the reduction tree doubles, and doubling is cheaper there.
+struct XyzzK256 {
+  FeK256 x, y, zz, zzz;
+};
+ECGPU_HD void xyzz_set_infinity(XyzzK256& p) { k256::set_zero(p.x); k256::set_zero(p.y); k256::set_zero(p.zz); k256::set_zero(p.zzz); }
+// p += (x2, y2), an affine point that is not the identity.  Exceptional cases by control flow: p at infinity, the same
+// point (doubling), opposite points (infinity).
+ECGPU_HD void xyzz_add_mixed(XyzzK256& p, const FeK256& x2, const FeK256& y2) {
+  using namespace k256;
+  if (is_zero(p.zz)) {
+    p.x = x2; p.y = y2; set_one(p.zz); set_one(p.zzz);
+    return;
+  }
+  FeK256 pp, r, t, q;
+  mul(pp, x2, p.zz); sub(pp, pp, p.x);           // P = U2 - X1
+  mul(r, y2, p.zzz); sub(r, r, p.y);             // R = S2 - Y1
+  if (__builtin_expect(is_zero(pp), 0)) {
+    if (is_zero(r)) {                             // same point: 2 (x2, y2), brought from Jacobian (X, Y, Z) to (X, Y, Z^2, Z^3)
+      JacK256 d;
+      jac_double_affine(d, x2, y2);
+      p.x = d.x; p.y = d.y;
+      sqr(p.zz, d.z); mul(p.zzz, p.zz, d.z);
+    } else {
+      xyzz_set_infinity(p);
+    }
+    return;
+  }
+  sqr(t, pp);                                    // PP
+  mul(q, p.x, t);                                // Q = X1 PP
+  mul(p.zz, p.zz, t);                            // ZZ3 = ZZ1 PP
+  mul(t, t, pp);                                 // PPP
+  mul(p.zzz, p.zzz, t);                          // ZZZ3 = ZZZ1 PPP
+  sqr(pp, r);
+  sub(pp, pp, t); sub(pp, pp, q); sub(p.x, pp, q);   // X3 = R^2 - PPP - 2Q
+  mul(t, p.y, t);                                // Y1 PPP
+  sub(q, q, p.x); mul(q, r, q);                  // R (Q - X3)
+  sub(p.y, q, t);
+}
+ECGPU_HD void xyzz_to_jacobian(JacK256& r, const XyzzK256& p) {
+  k256::mul(r.x, p.x, p.zz);
+  k256::mul(r.y, p.y, p.zzz);
+  r.z = p.zz;
 }
 
 }  // namespace msm

@@ -134,3 +134,26 @@ def test_heavy_buckets_equal_scalars(curve):
     want = CO.msm_naive(0, sc, pts)
     got = cv.msm(sc, pts)
     assert bytes(got) == bytes(want[:64])
+
+
+def test_slabs_of_a_large_sum():
+    """Sums above 2^24 terms run in slabs whose window sums are added (a sorted entry keeps the term index in 24 bits).
+    ECGPU_MSM_SLAB shrinks the slab so that the loop - three slabs, the last one ragged - runs on 2^16 + 777 terms."""
+    import os
+    import ecgpu
+    os.environ["ECGPU_MSM_SMALL"] = "0"
+    os.environ["ECGPU_MSM_SLAB"] = "30000"
+    try:
+        ctx = ecgpu.Context(0)
+        cv = ctx.curve("k256")
+        n = (1 << 16) + 777
+        s = CO.synth_scalars(0, n, synth.SEED, 123)
+        p = CO.synth_points(0, n, synth.SEED, 123)
+        p[40000] = 0
+        s[50000] = 0
+        want = CO.msm_naive(0, s, p)
+        assert bytes(cv.msm(s, p)) == bytes(want[:64]) and want[64] == 0
+        ctx.close()
+    finally:
+        os.environ.pop("ECGPU_MSM_SMALL", None)
+        os.environ.pop("ECGPU_MSM_SLAB", None)
