@@ -471,8 +471,12 @@ static void mfe_sub(const mcurve* c, mfe* r, const mfe* a, const mfe* b) { /* p2
   u64 m = bw ? ~(u64)0 : 0, carry = 0;
   for (int i = 0; i < c->nl; i++) { u128 s = (u128)d[i] + (c->p[i] & m) + carry; r->w[i] = (u64)s; carry = (u64)(s >> 64); }
 }
-/* a*b*R^-1 mod p: schoolbook product then word-by-word Montgomery reduction
- * (p256 field.rs:293-319 + :240-277; for p384 the same thing fiat_p384_mul computes). */
+/* a*b*R^-1 mod p: schoolbook product (p256 field.rs:293-319) then word-by-word Montgomery reduction.
+ * P-256 takes the reference's shortcuts (field.rs:240-277): the Montgomery constant is 1, so the quotient digit of round
+ * i is the word r_i itself; p[0] = 2^64 - 1 makes k*p[0] + r_i = k*2^64 (word i becomes zero and the carry into word
+ * i + 1 is k); p[2] = 0 needs no product at all.  Two multiplications per round instead of five.
+ * P-384 does the plain word-by-word reduction with m' = 0x100000001 - the work fiat_p384_mul does (p384_64.rs:146-868:
+ * 36 products for a*b and 36 for the multiples of p). */
 static void mfe_mul(const mcurve* c, mfe* r, const mfe* a, const mfe* b) {
   const int nl = c->nl;
   u64 t[2 * MAXL + 1];
@@ -483,11 +487,27 @@ static void mfe_mul(const mcurve* c, mfe* r, const mfe* a, const mfe* b) {
     t[i + nl] = carry;
   }
   u64 top = 0;
-  for (int i = 0; i < nl; i++) {
-    u64 m = t[i] * c->minv, carry = 0;
-    for (int j = 0; j < nl; j++) { u128 s = (u128)m * c->p[j] + t[i + j] + carry; t[i + j] = (u64)s; carry = (u64)(s >> 64); }
-    for (int k = i + nl; k < 2 * nl; k++) { u128 s = (u128)t[k] + carry; t[k] = (u64)s; carry = (u64)(s >> 64); }
-    top += carry;
+  if (c->minv == 1 && c->p[0] == ~(u64)0 && c->p[2] == 0) {   /* the P-256 base field: p' = 1, p[0] = 2^64 - 1, p[2] = 0 */
+    u64 carry2 = 0;
+    for (int i = 0; i < 4; i++) {
+      const u64 k = t[i];
+      u128 s = (u128)k * c->p[1] + t[i + 1] + k;                       /* mac(r1, r0, modulus[1], r0) */
+      t[i + 1] = (u64)s; u64 carry = (u64)(s >> 64);
+      s = (u128)t[i + 2] + carry;                                        /* adc(r2, 0, carry): p[2] = 0 */
+      t[i + 2] = (u64)s; carry = (u64)(s >> 64);
+      s = (u128)k * c->p[3] + t[i + 3] + carry;                          /* mac(r3, r0, modulus[3], carry) */
+      t[i + 3] = (u64)s; carry = (u64)(s >> 64);
+      s = (u128)t[i + 4] + carry2 + carry;                               /* adc(r4, carry2, carry) */
+      t[i + 4] = (u64)s; carry2 = (u64)(s >> 64);
+    }
+    top = carry2;
+  } else {
+    for (int i = 0; i < nl; i++) {
+      u64 m = t[i] * c->minv, carry = 0;
+      for (int j = 0; j < nl; j++) { u128 s = (u128)m * c->p[j] + t[i + j] + carry; t[i + j] = (u64)s; carry = (u64)(s >> 64); }
+      for (int k = i + nl; k < 2 * nl; k++) { u128 s = (u128)t[k] + carry; t[k] = (u64)s; carry = (u64)(s >> 64); }
+      top += carry;
+    }
   }
   u64 d[MAXL], bw = 0;
   for (int i = 0; i < nl; i++) { u128 s = (u128)t[nl + i] - c->p[i] - bw; d[i] = (u64)s; bw = (u64)(s >> 64) & 1; }
@@ -506,7 +526,7 @@ static void mfe_to_bytes(const mcurve* c, u8* b, const mfe* a) { /* to_canonical
   for (int i = 0; i < c->nl; i++) for (int j = 0; j < 8; j++) b[8 * (c->nl - 1 - i) + j] = (u8)(t.w[i] >> (56 - 8 * j));
 }
 static int mfe_is_zero(const mcurve* c, const mfe* a) { u64 z = 0; for (int i = 0; i < c->nl; i++) z |= a->w[i]; return z == 0; }
-static void mfe_pow(const mcurve* c, mfe* r, const mfe* a, const u64* e) { /* left-to-right square-and-multiply */
+static void mfe_pow(const mcurve* c, mfe* r, const mfe* a, const u64* e) { /* left-to-right square-and-multiply (input synthesis only) */
   mfe acc; memset(&acc, 0, sizeof(acc)); memcpy(acc.w, c->one, sizeof(u64) * c->nl);
   for (int i = c->nl * 64 - 1; i >= 0; i--) {
     mfe_mul(c, &acc, &acc, &acc);
@@ -514,9 +534,52 @@ static void mfe_pow(const mcurve* c, mfe* r, const mfe* a, const u64* e) { /* le
   }
   *r = acc;
 }
-static void mfe_invert(const mcurve* c, mfe* r, const mfe* a) { /* a^(p-2): p256 field.rs:357-382; unique inverse */
-  u64 e[MAXL]; memcpy(e, c->p, sizeof(e)); e[0] -= 2;
-  mfe_pow(c, r, a, e);
+/* acc = acc^(2^k) * m */
+static void mfe_sqn_mul(const mcurve* c, mfe* acc, int k, const mfe* m) {
+  while (k--) mfe_mul(c, acc, acc, acc);
+  if (m) mfe_mul(c, acc, acc, m);
+}
+/* a^(p-2), the unique inverse, by a fixed addition chain.  P-256: the chain of p256 field.rs:357-382 (255 squarings +
+ * 12 multiplications).  P-384: the reference inverts with Bernstein-Yang divsteps (p384 field.rs:67-91, ~1 100 divsteps on
+ * 6-limb values, roughly the cost of 120-150 field multiplications); a port of fiat's divstep is out of proportion for one
+ * call per scalar multiplication, so the oracle uses the Fermat chain for p - 2 = [255 ones][0][32 ones][64 zeros][30 ones]
+ * [0][1] (385 squarings + 14 multiplications): the same field element, ~4 % more work per P-384 scalar multiplication
+ * than the reference - the cpu_baseline for P-384 is that much pessimistic. */
+static void mfe_invert(const mcurve* c, mfe* r, const mfe* a) {
+  if (c != &P256C && c != &P384C) {                 /* the scalar fields (ECDSA): plain a^(n-2) */
+    u64 e[MAXL]; memcpy(e, c->p, sizeof(e)); e[0] -= 2;
+    mfe_pow(c, r, a, e);
+    return;
+  }
+  mfe x2 = *a, x3, x6, x12, x15, t;
+  mfe_sqn_mul(c, &x2, 1, a);
+  x3 = x2; mfe_sqn_mul(c, &x3, 1, a);
+  x6 = x3; mfe_sqn_mul(c, &x6, 3, &x3);
+  x12 = x6; mfe_sqn_mul(c, &x12, 6, &x6);
+  x15 = x12; mfe_sqn_mul(c, &x15, 3, &x3);
+  if (c == &P256C) {
+    mfe x16 = x15, x32, x47;
+    mfe_sqn_mul(c, &x16, 1, a);
+    x32 = x16; mfe_sqn_mul(c, &x32, 16, &x16);
+    t = x32; mfe_sqn_mul(c, &t, 15, NULL);          /* i53 = x32 << 15 */
+    mfe_mul(c, &x47, &t, &x15);
+    mfe_sqn_mul(c, &t, 17, a);
+    mfe_sqn_mul(c, &t, 143, &x47);
+    mfe_sqn_mul(c, &t, 47, &x47);
+    mfe_sqn_mul(c, &t, 2, a);
+  } else {
+    mfe x30 = x15, x32, x60, x120;
+    mfe_sqn_mul(c, &x30, 15, &x15);
+    x32 = x30; mfe_sqn_mul(c, &x32, 2, &x2);
+    x60 = x30; mfe_sqn_mul(c, &x60, 30, &x30);
+    x120 = x60; mfe_sqn_mul(c, &x120, 60, &x60);
+    t = x120; mfe_sqn_mul(c, &t, 120, &x120);       /* x240 */
+    mfe_sqn_mul(c, &t, 15, &x15);                   /* x255 */
+    mfe_sqn_mul(c, &t, 33, &x32);
+    mfe_sqn_mul(c, &t, 94, &x30);
+    mfe_sqn_mul(c, &t, 2, a);
+  }
+  *r = t;
 }
 
 typedef struct { mfe x, y, z; } mpt;

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Fold the counter CSV of tools/ct_evidence.py: per kernel, the counters of its consecutive dispatches (scalar sets
+"all ones", "all sevens", random).  python tools/ct_summarize.py gpurun_out/ct > profiles/r02_ct_counters.txt"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+rows = []
+for path in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    with open(path) as f:
+        rows += list(csv.DictReader(f))
+per = defaultdict(lambda: defaultdict(float))       # (dispatch, kernel) -> counter -> value
+for r in rows:
+    per[(int(r["Dispatch_Id"]), r["Kernel_Name"].split("(")[0])][r["Counter_Name"]] += float(r["Counter_Value"])
+by_kernel = defaultdict(list)
+for (d, k), c in sorted(per.items()):
+    by_kernel[k].append((d, c))
+for k, lst in by_kernel.items():
+    if not any(t in k for t in ("mul_gen_ref", "lincomb_ref", "mul_kernel", "mul_fast", "mul_wide")):
+        continue
+    names = sorted(lst[0][1])
+    print(k)
+    for d, c in lst:
+        print("   dispatch %4d  " % d + "  ".join("%s=%d" % (nm, c[nm]) for nm in names))
+    same = all(all(c[nm] == lst[0][1][nm] for nm in names) for _, c in lst)
+    print("   -> counters identical across the scalar sets: %s" % same)

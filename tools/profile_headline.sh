@@ -9,7 +9,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/headline
 rm -rf "$OUT"; mkdir -p "$OUT"
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs ${BENCH_ARGS:-}"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/trace.log" 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES" \
            "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY"; do
@@ -19,3 +19,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU S
 done
 python3 tools/pmc_summarize.py "$OUT" "${KERNEL_MATCH:-k256_mul_fast_kernel}" > gpurun_out/pmc_summary.json
 cat gpurun_out/pmc_summary.json
+cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" gpurun_out/headline_kernel_stats.csv
+# constant-time evidence: per-dispatch instruction counters of the reference schedules on three very different scalar sets
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d gpurun_out/ct -- python3 tools/ct_evidence.py > gpurun_out/ct.log 2>&1
+python3 tools/ct_summarize.py gpurun_out/ct > gpurun_out/ct_counters.txt
+cat gpurun_out/ct_counters.txt
