@@ -1,0 +1,113 @@
+// Multi-scalar multiplication: sum_i k_i * P_i for one large n (Pippenger bucket method), all three curves.
+//
+// The reference's form of this operation is lincomb_ext over a slice (k256/src/arithmetic/mul.rs:325-393), a Straus
+// interleaving with two 8-point tables per term - O(n) table memory and 128 shared doublings, unusable at 2^20..2^26
+// terms; the primeorder curves only have the two-term default (primeorder/src/projective.rs:415-420).  The result is
+// the same group element; the schedule here is
+//   0. secp256k1: the GLV split of every scalar (decompose_scalar, mul.rs:260-268: k = k1 + k2 lambda, |k1|, |k2| < 2^128),
+//      so a term is two half-terms (k1, P) and (k2, lambda P = (beta x, y)) and there are 8 windows instead of 16: half the
+//      buckets to reduce and 128 instead of 256 doublings in the serial tail, for the same number of bucket additions.
+//      P-256 / P-384 have no such endomorphism: one half, 16 / 24 windows; k > n/2 is replaced by n - k and -P so that the
+//      carry window of the signed recoding stays almost empty.
+//   1. signed c-bit digits of every (half-)scalar, computed once (c = 16, 2^15 buckets per window); the points are brought
+//      to the field's internal form once as well (for the NIST curves that is the conversion to Montgomery form)
+//   2. two-level counting sort of the (half-term, window) entries by bucket (512 coarse bins, then 64 buckets within a
+//      bin; LDS-privatised counters at both levels, msm_kernels.hpp)
+//   3. bucket sums in XYZZ coordinates (mixed addition 8M + 2S), a bucket's run cut into parts for neighbouring lanes;
+//      exceptional cases handled, buckets with very many entries summed by whole workgroups
+//   4. per window sum_j j*B_j by segmented running sums, then Horner over the windows
+// Every stage is a kernel over device memory; no host round trips until the final point.
+#pragma once
+#include "jacobian.hpp"
+#include "mulfast_k256.hpp"
+
+namespace ecgpu {
+namespace msm {
+
+constexpr int CBITS = 16;                     // window bits
+constexpr int NBUCKET = 1 << (CBITS - 1);     // |digit| in 1..2^15
+// bucket reduction tree: 2^15 buckets = NSEG1 x SEG1 x SEG0 per window.  Short runs keep the dependent chains of the
+// two segment kernels short (16 and 32 additions); the window kernel finishes with LDS tree sums over NSEG1 lanes.
+constexpr int LOG_SEG0 = 3, SEG0 = 1 << LOG_SEG0;     // buckets per level-0 run
+constexpr int LOG_SEG1 = 4, SEG1 = 1 << LOG_SEG1;     // level-0 results per level-1 run
+constexpr int NSEG0 = NBUCKET / SEG0;                 // level-0 runs per window (4096)
+constexpr int LOG_NSEG1 = CBITS - 1 - LOG_SEG0 - LOG_SEG1;
+constexpr int NSEG1 = 1 << LOG_NSEG1;                 // level-1 runs per window (256)
+constexpr int SUMW_LEN = NSEG0 / NSEG1, NSUMW = NSEG1;  // partial sums of the level-0 weighted parts, one per window-kernel lane
+
+// per-curve shape of the digit matrix
+template <class C>
+struct Cfg {
+  static constexpr int NHALF = C::A_IS_ZERO ? 2 : 1;                               // GLV halves per term (secp256k1 only)
+  static constexpr int NWIN = (C::A_IS_ZERO ? 8 : 2 * C::NW) + 1;                  // 16-bit windows of a (half-)scalar + the carry window
+  static constexpr int NDIG = NWIN * NHALF;                                        // digit columns per term
+};
+
+// doubling and general addition on Jacobian triples: secp256k1 keeps its own doubling (funnel-shift small multiples)
+template <class C>
+ECGPU_HD void pt_dbl(Jac<C>& p) { jac::dbl<C>(p); }
+template <>
+ECGPU_HD void pt_dbl<CurveK256>(Jac<CurveK256>& p) {
+  JacK256 t;
+  t.x = p.x; t.y = p.y; t.z = p.z;
+  k256::jac_double(t);
+  p.x = t.x; p.y = t.y; p.z = t.z;
+}
+template <class C>
+ECGPU_HD void pt_add(Jac<C>& r, const Jac<C>& p, const Jac<C>& q) { jac::add<C>(r, p, q); }
+
+// XYZZ coordinates for the bucket accumulators: x = X / ZZ, y = Y / ZZZ with ZZ^3 = ZZZ^2, infinity <=> ZZ = 0.
+// Adding an affine point costs 8M + 2S (madd-2008-s, independent of the curve coefficients), one squaring less than the
+// Jacobian mixed addition; the 134 M bucket additions of a 2^23-term sum are where that squaring counts.  Buckets leave the
+// accumulation as Jacobian triples (X ZZ, Y ZZZ, ZZ) - two multiplications - because the reduction tree doubles, and
+// doubling is cheaper there.
+template <class C>
+struct Xyzz {
+  typename C::Fe x, y, zz, zzz;
+};
+template <class C>
+ECGPU_HD void xyzz_set_infinity(Xyzz<C>& p) { C::fe_zero(p.x); C::fe_zero(p.y); C::fe_zero(p.zz); C::fe_zero(p.zzz); }
+// p += (x2, y2), an affine point (internal field form) that is not the identity.  Exceptional cases by control flow:
+// p at infinity, the same point (doubling), opposite points (infinity).
+template <class C>
+ECGPU_HD void xyzz_add_mixed(Xyzz<C>& p, const typename C::Fe& x2, const typename C::Fe& y2) {
+  using Fe = typename C::Fe;
+  if (C::fe_is_zero(p.zz)) {
+    p.x = x2; p.y = y2; C::fe_one(p.zz); C::fe_one(p.zzz);
+    return;
+  }
+  Fe pp, r, t, q;
+  C::fe_mul(pp, x2, p.zz); C::fe_sub(pp, pp, p.x);           // P = U2 - X1
+  C::fe_mul(r, y2, p.zzz); C::fe_sub(r, r, p.y);             // R = S2 - Y1
+  if (__builtin_expect(C::fe_is_zero(pp), 0)) {
+    if (C::fe_is_zero(r)) {                       // same point: 2 (x2, y2), brought from Jacobian (X, Y, Z) to (X, Y, Z^2, Z^3)
+      Jac<C> d;
+      d.x = x2; d.y = y2; C::fe_one(d.z);
+      pt_dbl<C>(d);
+      p.x = d.x; p.y = d.y;
+      C::fe_sqr(p.zz, d.z); C::fe_mul(p.zzz, p.zz, d.z);
+    } else {
+      xyzz_set_infinity<C>(p);
+    }
+    return;
+  }
+  C::fe_sqr(t, pp);                                          // PP
+  C::fe_mul(q, p.x, t);                                      // Q = X1 PP
+  C::fe_mul(p.zz, p.zz, t);                                  // ZZ3 = ZZ1 PP
+  C::fe_mul(t, t, pp);                                       // PPP
+  C::fe_mul(p.zzz, p.zzz, t);                                // ZZZ3 = ZZZ1 PPP
+  C::fe_sqr(pp, r);
+  C::fe_sub(pp, pp, t); C::fe_sub(pp, pp, q); C::fe_sub(p.x, pp, q);   // X3 = R^2 - PPP - 2Q
+  C::fe_mul(t, p.y, t);                                      // Y1 PPP
+  C::fe_sub(q, q, p.x); C::fe_mul(q, r, q);                  // R (Q - X3)
+  C::fe_sub(p.y, q, t);
+}
+template <class C>
+ECGPU_HD void xyzz_to_jacobian(Jac<C>& r, const Xyzz<C>& p) {
+  C::fe_mul(r.x, p.x, p.zz);
+  C::fe_mul(r.y, p.y, p.zzz);
+  r.z = p.zz;
+}
+
+}  // namespace msm
+}  // namespace ecgpu

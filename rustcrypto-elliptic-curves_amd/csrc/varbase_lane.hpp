@@ -26,7 +26,10 @@ struct LaneWs {
   typename C::Fe pre[BATCH * 8];
 };
 
-// One pass of one lane: units base, base + T, .., base + (BATCH - 1) T (those below n).
+// One pass of one lane: units base, base + T, .., base + (BATCH / NT - 1) T (those below n).  A unit is a linear
+// combination of NT terms (NT = 1: k * P; NT = 2: LinearCombination::lincomb, k P + l Q, primeorder/src/projective.rs:
+// 415-420 - the reference computes the two products separately; here they share the doublings of one window loop);
+// term t of unit i is scalar / point number i * NT + t, and the NT tables of a unit take NT of the BATCH table slots.
 // Per-lane tables live in a lane-contiguous global workspace (in the private segment a lane-divergent index turns
 // every entry read into scattered dword rows: 3.5x the fetch traffic on the k256 kernel).
 // The BATCH tables of a pass are built first and brought to affine form with ONE inversion (Montgomery's trick over
@@ -34,31 +37,35 @@ struct LaneWs {
 // (8M + 3S instead of 11M + 5S).
 // Measured: +6 % for P-384, -1.4 % for P-256 (whose multiplication is cheap enough that the extra pass over the
 // tables costs what the cheaper additions save), hence the switch.
-template <class C, int BATCH>
+template <class C, int BATCH, int NT = 1>
 ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf, size_t n, size_t base,
                         size_t T, LaneWs<C, BATCH>& ws) {
+  static_assert(BATCH % NT == 0 && BATCH <= 32, "table slots per pass");
   constexpr int NW = C::NW;
+  constexpr int UB = BATCH / NT;               // units per pass
   using Fe = typename C::Fe;
   constexpr bool AFFINE_TABLES = (C::NW > 8);
-  Jac<C> res[BATCH];
-  Fe pre[BATCH];
+  Jac<C> res[UB];
+  Fe pre[UB];
   const int pw = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * NW;
   int cnt = 0;
-  u32 flips = 0, infs = 0;
-  // ---- phase A: Jacobian tables [P .. 8P] of the units of this pass
+  u32 flips = 0, infs = 0;                     // one bit per table slot
+  // ---- phase A: Jacobian tables [P .. 8P] of the terms of this pass
 #pragma unroll 1
-  for (int b = 0; b < BATCH; b++) {
+  for (int s = 0; s < BATCH; s++) {
+    const int b = s / NT;
     const size_t i = base + (size_t)b * T;
     if (i >= n) break;
     cnt = b + 1;
+    const size_t term = i * NT + (size_t)(s % NT);
     u32 k[NW], ord[NW], t[NW];
-    C::scalar_load(k, scalars + i * NW);
+    C::scalar_load(k, scalars + term * NW);
     C::order(ord);
     reduce_once<NW>(k, ord);
     mp_sub<NW>(t, ord, k);
     const bool flip = !mp_geq<NW>(t, k);          // n - k < k: use n - k and -P
     // input point -> Jacobian (homogeneous X:Y:Z is Jacobian XZ : YZ^2 : Z)
-    const u32* src = points + i * pw;
+    const u32* src = points + term * pw;
     Jac<C> p;
     C::fe_load(p.x, src);
     C::fe_load(p.y, src + NW);
@@ -77,15 +84,15 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
       p_inf = (z == 0);
       C::fe_one(p.z);
     }
-    if (p_inf) {                                // keep the arithmetic on a valid point; the result is replaced below
+    if (p_inf) {                                // keep the arithmetic on a valid point; the term is left out below
       typename C::Pt g;
       C::pt_generator(g);
       p.x = g.x; p.y = g.y; C::fe_one(p.z);
     }
     if (flip) C::fe_neg(p.y, p.y);
-    flips |= (flip ? 1u : 0u) << b;
-    infs |= (p_inf ? 1u : 0u) << b;
-    Jac<C>* tab = ws.tab[b];
+    flips |= (flip ? 1u : 0u) << s;
+    infs |= (p_inf ? 1u : 0u) << s;
+    Jac<C>* tab = ws.tab[s];
     Jac<C> p2 = p, t3, u;
     jac::dbl<C>(p2);                       // 2P
     tab[0] = p; tab[1] = p2;
@@ -102,12 +109,12 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
     jac::dbl<C>(p2);                       // 8P
     tab[7] = p2;
   }
-  // ---- phase B: all cnt * 8 entries to affine with one inversion (a zero denominator - only possible for input
+  // ---- phase B: all cnt * NT * 8 entries to affine with one inversion (a zero denominator - only possible for input
   //      that is not on the curve - is replaced by one so that it cannot poison its neighbours)
   if constexpr (AFFINE_TABLES) {
     Fe acc; C::fe_one(acc);
 #pragma unroll 1
-    for (int e = 0; e < cnt * 8; e++) {
+    for (int e = 0; e < cnt * NT * 8; e++) {
       ws.pre[e] = acc;
       Fe z = ws.tab[e >> 3][e & 7].z;
       if (C::fe_is_zero(z)) C::fe_one(z);
@@ -116,7 +123,7 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
     Fe ai;
     C::fe_inv(ai, acc);
 #pragma unroll 1
-    for (int e = cnt * 8 - 1; e >= 0; e--) {
+    for (int e = cnt * NT * 8 - 1; e >= 0; e--) {
       Jac<C>& q = ws.tab[e >> 3][e & 7];
       Fe z = q.z, zi, t;
       if (C::fe_is_zero(z)) C::fe_one(z);
@@ -128,48 +135,68 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
       C::fe_mul(q.y, q.y, t);
     }
   }
-  // ---- phase C: signed 4-bit windows over the affine tables
+  // ---- phase C: signed 4-bit windows over the tables; the NT terms of a unit share the doublings
 #pragma unroll 1
   for (int b = 0; b < cnt; b++) {
     const size_t i = base + (size_t)b * T;
-    u32 k[NW], ord[NW], t[NW];
-    C::scalar_load(k, scalars + i * NW);
-    C::order(ord);
-    reduce_once<NW>(k, ord);
-    if ((flips >> b) & 1u) { mp_sub<NW>(t, ord, k); mp_copy<NW>(k, t); }
-    const Jac<C>* tab = ws.tab[b];
     // signed nibbles: digit_j = nibble_j(k + 0x88..8) - 8, the carry out of the top nibble is the last digit
-    u32 y[NW], c = 0;
+    u32 y[NT][NW], carry[NT];
 #pragma unroll
-    for (int w = 0; w < NW; w++) y[w] = addc(k[w], 0x88888888u, c);
+    for (int tt = 0; tt < NT; tt++) {
+      const int s = b * NT + tt;
+      u32 k[NW], ord[NW], t[NW];
+      C::scalar_load(k, scalars + (i * NT + tt) * NW);
+      C::order(ord);
+      reduce_once<NW>(k, ord);
+      if ((flips >> s) & 1u) { mp_sub<NW>(t, ord, k); mp_copy<NW>(k, t); }
+      u32 c = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) y[tt][w] = addc(k[w], 0x88888888u, c);
+      if ((infs >> s) & 1u) {                   // an identity input contributes nothing: all its digits read as zero
+        c = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) y[tt][w] = 0x88888888u;
+      }
+      carry[tt] = c;
+    }
     Jac<C> acc;
     jac::set_infinity<C>(acc);
-    if (c) {
-      acc = tab[0];
-      if constexpr (AFFINE_TABLES) C::fe_one(acc.z);
-    }
 #pragma unroll 1
-    for (int j = 8 * NW - 1; j >= 0; j--) {
+    for (int j = 8 * NW; j >= 0; j--) {         // position 8 NW holds the carry digits (0 or 1)
+      if (j != 8 * NW) {
 #pragma unroll 1
-      for (int d = 0; d < 4; d++) jac::dbl<C>(acc);
-      u32 word = y[0];
+        for (int d = 0; d < 4; d++) jac::dbl<C>(acc);
+      }
+#pragma unroll 1
+      for (int tt = 0; tt < NT; tt++) {
+        int sd;
+        if (j == 8 * NW) {
+          sd = 0;
 #pragma unroll
-      for (int q = 1; q < NW; q++) word = (j >> 3) == q ? y[q] : word;
-      const int sd = (int)((word >> (4 * (j & 7))) & 15u) - 8;
-      if (sd != 0) {
-        if constexpr (AFFINE_TABLES) {
-          const Jac<C>& e = tab[(sd < 0 ? -sd : sd) - 1];
-          Fe ex = e.x, ey = e.y;
-          if (sd < 0) C::fe_neg(ey, ey);
-          jac::add_mixed<C>(acc, ex, ey);
+          for (int q = 0; q < NT; q++) sd = (q == tt) ? (int)carry[q] : sd;
         } else {
-          Jac<C> e = tab[(sd < 0 ? -sd : sd) - 1];
-          if (sd < 0) C::fe_neg(e.y, e.y);
-          jac::add<C>(acc, acc, e);
+          u32 word = y[0][0];
+#pragma unroll
+          for (int r = 0; r < NT; r++)
+#pragma unroll
+            for (int q = 0; q < NW; q++) word = (r == tt && (j >> 3) == q) ? y[r][q] : word;
+          sd = (int)((word >> (4 * (j & 7))) & 15u) - 8;
+        }
+        if (sd != 0) {
+          const Jac<C>* tab = ws.tab[b * NT + tt];
+          if constexpr (AFFINE_TABLES) {
+            const Jac<C>& e = tab[(sd < 0 ? -sd : sd) - 1];
+            Fe ex = e.x, ey = e.y;
+            if (sd < 0) C::fe_neg(ey, ey);
+            jac::add_mixed<C>(acc, ex, ey);
+          } else {
+            Jac<C> e = tab[(sd < 0 ? -sd : sd) - 1];
+            if (sd < 0) C::fe_neg(e.y, e.y);
+            jac::add<C>(acc, acc, e);
+          }
         }
       }
     }
-    if ((infs >> b) & 1u) jac::set_infinity<C>(acc);
     res[b] = acc;
   }
   jac::store_batch_affine<C>(res, pre, cnt, base, T, out, out_fmt, out_inf);

@@ -143,27 +143,13 @@ int ht_k256_jac_double(const uint8_t* p, uint8_t* out, int n) {
 }
 
 // ---- MSM primitive: general Jacobian addition with exceptional cases ------------------------------
-#include "msm_k256.hpp"
+#include "msm.hpp"
 extern "C" int ht_k256_jac_add(const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
   for (int i = 0; i < n; i++) {
-    JacK256 a, b, r;
+    Jac<CurveK256> a, b, r;
     load(a.x, p + 96 * i); load(a.y, p + 96 * i + 32); load(a.z, p + 96 * i + 64);
     load(b.x, q + 96 * i); load(b.y, q + 96 * i + 32); load(b.z, q + 96 * i + 64);
-    msm::jac_add(r, a, b);
-    store(out + 96 * i, r.x); store(out + 96 * i + 32, r.y); store(out + 96 * i + 64, r.z);
-  }
-  return 0;
-}
-// XYZZ bucket accumulator of the MSM (msm_k256.hpp): p (X||Y||ZZ||ZZZ, 128 B) += q (affine x||y), then the conversion to
-// the Jacobian triple the reduction tree works on; out = X||Y||Z (96 B, x = X/Z^2, y = Y/Z^3)
-extern "C" int ht_k256_xyzz_add_mixed(const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
-  for (int i = 0; i < n; i++) {
-    msm::XyzzK256 a;
-    load(a.x, p + 128 * i); load(a.y, p + 128 * i + 32); load(a.zz, p + 128 * i + 64); load(a.zzz, p + 128 * i + 96);
-    FeK256 x, y; load(x, q + 64 * i); load(y, q + 64 * i + 32);
-    msm::xyzz_add_mixed(a, x, y);
-    JacK256 r;
-    msm::xyzz_to_jacobian(r, a);
+    msm::pt_add<CurveK256>(r, a, b);
     store(out + 96 * i, r.x); store(out + 96 * i + 32, r.y); store(out + 96 * i + 64, r.z);
   }
   return 0;

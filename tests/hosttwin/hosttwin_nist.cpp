@@ -100,18 +100,47 @@ extern "C" int ht_jac_op(int curve, int op, const uint8_t* p, const uint8_t* q, 
 // The kernel gives lane tid the units tid, tid + T, ... in passes of BATCH; here T = lanes is small, so a few hundred
 // units exercise every slot count 1..BATCH, several passes, the shared table inversion and the batched output.
 #include "varbase_lane.hpp"
-template <class C>
+template <class C, int NT>
 static int vb_walk(const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, size_t lanes) {
   constexpr int BATCH = 8;
   vb::LaneWs<C, BATCH>* ws = (vb::LaneWs<C, BATCH>*)malloc(sizeof(vb::LaneWs<C, BATCH>));
   for (size_t tid = 0; tid < lanes; tid++)
-    for (size_t base = tid; base < n; base += lanes * BATCH)
-      vb::lane_pass<C, BATCH>((const u32*)scalars, (const u32*)points, pt_fmt, (u32*)out, out_fmt, out_inf, n, base, lanes, *ws);
+    for (size_t base = tid; base < n; base += lanes * (BATCH / NT))
+      vb::lane_pass<C, BATCH, NT>((const u32*)scalars, (const u32*)points, pt_fmt, (u32*)out, out_fmt, out_inf, n, base, lanes, *ws);
   free(ws);
   return 0;
 }
+// n units of `terms` (1 or 2) terms each
+extern "C" int ht_vb_lincomb(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, int terms, uint8_t* out, int out_fmt, uint8_t* out_inf,
+                             size_t n, size_t lanes) {
+  if (terms == 2)
+    return curve == 1 ? vb_walk<CurveP256, 2>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes)
+                      : vb_walk<CurveP384, 2>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
+  return curve == 1 ? vb_walk<CurveP256, 1>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes)
+                    : vb_walk<CurveP384, 1>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
+}
 extern "C" int ht_vb_mul(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
                          size_t lanes) {
-  return curve == 1 ? vb_walk<CurveP256>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes)
-                    : vb_walk<CurveP384>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
+  return ht_vb_lincomb(curve, scalars, points, pt_fmt, 1, out, out_fmt, out_inf, n, lanes);
+}
+
+// ---- XYZZ bucket accumulator of the MSM (msm.hpp) over any curve: p (X||Y||ZZ||ZZZ) += q (affine x||y), converted to the
+//      Jacobian triple the reduction tree works on; out = X||Y||Z
+#include "msm.hpp"
+template <class C>
+static int xyzz_op(const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
+  for (int i = 0; i < n; i++) {
+    msm::Xyzz<C> a;
+    load<C>(a.x, p + 4 * C::NB * i); load<C>(a.y, p + 4 * C::NB * i + C::NB); load<C>(a.zz, p + 4 * C::NB * i + 2 * C::NB); load<C>(a.zzz, p + 4 * C::NB * i + 3 * C::NB);
+    typename C::Fe x, y; load<C>(x, q + 2 * C::NB * i); load<C>(y, q + 2 * C::NB * i + C::NB);
+    msm::xyzz_add_mixed<C>(a, x, y);
+    Jac<C> r;
+    msm::xyzz_to_jacobian<C>(r, a);
+    store_jac<C>(out + 3 * C::NB * i, r);
+  }
+  return 0;
+}
+extern "C" int ht_xyzz_add_mixed(int curve, const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
+  if (curve == 0) return xyzz_op<CurveK256>(p, q, out, n);
+  return curve == 1 ? xyzz_op<CurveP256>(p, q, out, n) : xyzz_op<CurveP384>(p, q, out, n);
 }

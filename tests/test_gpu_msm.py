@@ -157,3 +157,77 @@ def test_slabs_of_a_large_sum():
     finally:
         os.environ.pop("ECGPU_MSM_SMALL", None)
         os.environ.pop("ECGPU_MSM_SLAB", None)
+
+
+def _oracle_sum(cid, c, s, p, threads=16):
+    """sum_i s_i P_i with the C oracle: one reference multiplication per term (threaded), complete additions in a tree."""
+    nb = c.nbytes
+    parts = CO.lincomb_batch(cid, s, p, out_proj=True, threads=threads)
+    ident = np.frombuffer(M.proj_bytes(c, M.IDENTITY), dtype=np.uint8)[None, :]
+    while parts.shape[0] > 1:
+        if parts.shape[0] % 2:
+            parts = np.concatenate([parts, ident])
+        parts = CO.point_op(cid, 0, parts[0::2].copy(), parts[1::2].copy())
+    X, Y, Z = (int.from_bytes(bytes(parts[0][nb * t:nb * (t + 1)]), "big") for t in range(3))
+    return M.to_affine(c, (X, Y, Z))
+
+
+@pytest.mark.parametrize("cn,cid", [("p256", 1), ("p384", 2)])
+@pytest.mark.parametrize("path", ["auto", "buckets"])
+def test_nist_msm(cn, cid, path):
+    """The bucket method on the curves without an endomorphism (one half-term per term, 16 / 24 windows, sign fold
+    k > n/2 -> n - k): edge cases against the big-integer model, 2^13 unstructured terms against the C oracle, and
+    2^18 structured terms P_i = (a0 + i d) G against the closed form (sum k_i (a0 + i d) mod n) G."""
+    import os
+    import torch
+    import ecgpu
+    c = M.CURVES[cn]
+    nb, n_ord = c.nbytes, c.n
+    if path == "buckets":
+        os.environ["ECGPU_MSM_SMALL"] = "0"
+    try:
+        ctx = ecgpu.Context(0)
+        cv = ctx.curve(cn)
+        G = (c.gx, c.gy)
+        rng = random.Random(64 + cid)
+        cases = [([5], [G]), ([0], [G]), ([n_ord - 1, 1], [G, G]), ([3, 3, 3], [G, G, G]), ([7, 9], [G, None]),
+                 ([(n_ord - 1) // 2, (n_ord + 1) // 2, n_ord - 2, 2**15, 2**16 - 1, 2**(8 * nb - 1) % n_ord, n_ord - 32768],
+                  [synth.point(c, i, seed=64) for i in range(7)]),
+                 ([rng.randrange(n_ord) for _ in range(200)], [synth.point(c, i, seed=65) for i in range(200)])]
+        for ks, pts in cases:
+            s = arr([M.i2b(c, k) for k in ks], nb)
+            p = arr([bytes(2 * nb) if q is None else M.i2b(c, q[0]) + M.i2b(c, q[1]) for q in pts], 2 * nb)
+            tot = None
+            for k, q in zip(ks, pts):
+                tot = M.affine_add(c, tot, None if q is None else M.affine_mul(c, k, q))
+            assert bytes(cv.msm(s, p)) == (bytes(2 * nb) if tot is None else M.i2b(c, tot[0]) + M.i2b(c, tot[1])), ks[:3]
+        n = 1 << 13
+        s = CO.synth_scalars(cid, n, synth.SEED, 77)
+        p = CO.synth_points(cid, n, synth.SEED, 77)
+        p[100] = 0
+        s[200] = 0
+        want = _oracle_sum(cid, c, s, p)
+        assert bytes(cv.msm(s, p)) == M.i2b(c, want[0]) + M.i2b(c, want[1])
+        got = cv.msm(s, p, out_format=ecgpu.PROJECTIVE)
+        assert bytes(got) == M.i2b(c, want[0]) + M.i2b(c, want[1]) + M.i2b(c, 1)
+        if path == "buckets":
+            # structured: 2^18 terms through the full-size pipeline
+            n = 1 << 18
+            a0, d = 0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321
+            vals = [a0 + i * d for i in range(n)]
+            d_v = torch.from_numpy(np.frombuffer(b"".join(v.to_bytes(nb, "big") for v in vals), dtype=np.uint8).reshape(n, nb).copy()).cuda()
+            d_pts = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+            cv.mul_device(d_v, None, d_pts, n)
+            ks = CO.synth_scalars(cid, n, synth.SEED, 0)
+            d_ks = torch.from_numpy(ks).cuda()
+            d_out = torch.empty((2 * nb,), dtype=torch.uint8, device="cuda")
+            ctx.synchronize()
+            cv.msm_device(d_ks, d_pts, n, d_out)
+            ctx.synchronize()
+            kb = ks.tobytes()
+            tot = sum(int.from_bytes(kb[nb * i:nb * i + nb], "big") * vals[i] for i in range(n)) % n_ord
+            w = M.affine_mul(c, tot, G)
+            assert bytes(d_out.cpu().numpy()) == M.i2b(c, w[0]) + M.i2b(c, w[1])
+        ctx.close()
+    finally:
+        os.environ.pop("ECGPU_MSM_SMALL", None)

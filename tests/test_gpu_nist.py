@@ -336,3 +336,29 @@ def test_fixed_base_wide_tables_ragged_sizes(ctx, cn, cid):
         want = CO.lincomb_batch(cid, s, None, threads=4)
         got = np.concatenate([d_o.cpu().numpy()[idx], d_i.cpu().numpy()[idx][:, None]], axis=1)
         assert bytes(got) == bytes(want), n
+
+
+@pytest.mark.parametrize("cn,cid", [("p256", 1), ("p384", 2)])
+def test_two_term_lincomb_throughput_schedule(ctx, cn, cid):
+    """LinearCombination::lincomb (k P + l Q, primeorder/src/projective.rs:415-420) on the throughput schedule: the two
+    terms share the doublings (varbase_lane.hpp, NT = 2).  4 097 units - several slots per lane only above 2^18, covered by
+    the host twin - with edge cases, against the C oracle's two reference multiplications and complete addition."""
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    cv = ctx.curve(cn)
+    n = 4097
+    s = CO.synth_scalars(cid, 2 * n, synth.SEED, 321)
+    p = CO.synth_points(cid, 2 * n, synth.SEED, 321)
+    s[4] = 0                      # a zero scalar
+    p[7] = 0                      # an identity point
+    p[11] = p[10]; s[11] = s[10]  # k P + k P: the doubling branch of the addition
+    p[13] = p[12]; s[13] = np.frombuffer(M.i2b(c, (c.n - int.from_bytes(bytes(s[12]), "big")) % c.n), dtype=np.uint8)   # k P - k P = identity
+    p[14] = 0; p[15] = 0          # both terms identity
+    out, inf = cv.lincomb(s, p, terms=2)
+    want = CO.lincomb_batch(cid, s, p, terms=2, threads=8)
+    assert bytes(np.concatenate([out, inf[:, None]], axis=1)) == bytes(want)
+    assert inf[6] == 1 and inf[7] == 1 and inf.sum() == 2
+    # and the exact-reference flag still gives the reference's own (X, Y, Z)
+    ref = cv.lincomb(s[:64], p[:64], terms=2, out_format=ecgpu.PROJECTIVE, flags=ecgpu.EXACT_REFERENCE)
+    xyz = cv.lincomb(s[:64], p[:64], terms=2, out_format=ecgpu.PROJECTIVE)
+    assert cv.point_eq(ref, xyz).all()

@@ -130,3 +130,46 @@ def test_primeorder_reference_schedule_scans_every_table_entry(cn, cid):
         assert bytes(out) == M.proj_bytes(c, M.primeorder_mul_ref(c, (c.G[0], c.G[1], 1), k))
     assert all(t == traces[0] for t in traces) and len(traces[0]) == 2 * nb * 15      # one 15-way scan per 4-bit window
     assert traces[0][:15] == list(range(1, 16))
+
+
+@pytest.mark.parametrize("cn,cid", CURVES)
+@pytest.mark.parametrize("lanes,n", [(3, 29), (1, 5)])
+def test_vb_two_term_lincomb_walk(cn, cid, lanes, n):
+    """LinearCombination::lincomb (k P + l Q) on the throughput schedule: the two terms of a unit share the doublings;
+    4 units per lane and pass.  Edge cases: a zero scalar, an identity point in either slot, P = Q, P = -Q (the sum of
+    the two products passes through the doubling / infinity branches of the Jacobian addition), scalars >= n."""
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    ks = [synth.scalar(c, 900 + i) for i in range(2 * n)]
+    ps = [synth.point(c, 900 + i) for i in range(2 * n)]
+    ks[2] = 0
+    ps[5] = None
+    if n > 8:
+        ps[8] = None
+        ps[13] = ps[12]
+        ks[13] = ks[12]                       # k P + k P
+        ps[15] = (ps[14][0], (-ps[14][1]) % c.p)
+        ks[15] = ks[14]                       # k P + k (-P) = identity
+        ks[16] = c.n + 7
+        ks[19] = c.n - 1
+        ks[18] = 1
+        ps[19] = ps[18]                       # P + (n - 1) P = identity
+        ps[20] = None
+        ps[21] = None                         # both terms identity
+    sb = b"".join(int(k).to_bytes(nb, "big") for k in ks)
+    pb = b"".join(M.i2b(c, p[0]) + M.i2b(c, p[1]) if p is not None else bytes(2 * nb) for p in ps)
+    out, inf = outbuf(2 * nb * n), outbuf(n)
+    L = lib()
+    L.ht_vb_lincomb.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                ctypes.c_size_t, ctypes.c_size_t]
+    assert L.ht_vb_lincomb(cid, buf(sb), buf(pb), 0, 2, out, 0, inf, n, lanes) == 0
+    o = bytes(out)
+    for i in range(n):
+        a = None if ps[2 * i] is None else M.affine_mul(c, ks[2 * i] % c.n, ps[2 * i])
+        b = None if ps[2 * i + 1] is None else M.affine_mul(c, ks[2 * i + 1] % c.n, ps[2 * i + 1])
+        want = M.affine_add(c, a, b)
+        got = o[2 * nb * i:2 * nb * (i + 1)]
+        if want is None:
+            assert got == bytes(2 * nb) and bytes(inf)[i] == 1, i
+        else:
+            assert got == M.i2b(c, want[0]) + M.i2b(c, want[1]) and bytes(inf)[i] == 0, i

@@ -59,15 +59,16 @@ def test_jacobian_ops(cn, cid):
         assert back(o, i) == M.affine_add(c, a, b), ("add", i)
 
 
-def test_k256_xyzz_bucket_accumulator():
-    """XYZZ mixed addition of the MSM bucket sums (msm_k256.hpp) and its conversion to Jacobian, with the exceptional
-    cases: accumulator at infinity, the same point (doubling), opposite points."""
-    c = M.K256
-    p = c.p
+@pytest.mark.parametrize("cn,cid", CURVES)
+def test_xyzz_bucket_accumulator(cn, cid):
+    """XYZZ mixed addition of the MSM bucket sums (msm.hpp, all curves) and its conversion to Jacobian, with the
+    exceptional cases: accumulator at infinity, the same point (doubling), opposite points."""
+    c = M.CURVES[cn]
+    p, nb = c.p, c.nbytes
     rng = random.Random(72)
 
     def fe(v):
-        return int(v % p).to_bytes(32, "big")
+        return int(v % p).to_bytes(nb, "big")
 
     def xyzz(A):
         if A is None:
@@ -79,10 +80,10 @@ def test_k256_xyzz_bucket_accumulator():
     pairs = [(pts[i], pts[i + 1]) for i in range(0, 36, 2)] + [(pts[0], pts[0]), (pts[1], M.affine_neg(c, pts[1])), (None, pts[2]), (pts[5], pts[5])]
     pin = b"".join(b"".join(fe(v) for v in xyzz(a)) for a, _ in pairs)
     qin = b"".join(fe(b[0]) + fe(b[1]) for _, b in pairs)
-    out = outbuf(96 * len(pairs))
-    assert lib().ht_k256_xyzz_add_mixed(buf(pin), buf(qin), out, len(pairs)) == 0
+    out = outbuf(3 * nb * len(pairs))
+    assert lib().ht_xyzz_add_mixed(cid, buf(pin), buf(qin), out, len(pairs)) == 0
     o = bytes(out)
     for i, (a, b) in enumerate(pairs):
-        X, Y, Z = (int.from_bytes(o[96 * i + 32 * t:96 * i + 32 * (t + 1)], "big") for t in range(3))
+        X, Y, Z = (int.from_bytes(o[3 * nb * i + nb * t:3 * nb * i + nb * (t + 1)], "big") for t in range(3))
         got = None if Z == 0 else (X * pow(Z, -2, p) % p, Y * pow(Z, -3, p) % p)
         assert got == M.affine_add(c, a, b), i

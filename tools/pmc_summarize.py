@@ -2,9 +2,12 @@
 """Fold the rocprofv3 outputs of tools/profile_headline.sh into one JSON summary (per-launch averages of
 every counter for the kernels whose name contains MATCH, plus the kernel-trace average duration).
 
-FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  On gfx950 FETCH_SIZE counts 64-byte requests as
-32 bytes for wide coalesced reads (MI355X_MICROARCH.md, HBM section): both the raw and the corrected (x2
-on the fetch side) figures are given.
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reads
+exactly half the bytes of a WIDE COALESCED STREAMING read (128-byte requests tallied at 64 B) and "other access widths
+are uncalibrated: calibrate on a known byte count in your own access pattern".  Pass the known read volume of the kernel
+as the third argument (bytes per launch) and the summary says which rule fits; for the scalar-multiplication kernels -
+lane-divergent 64-byte table blocks, 61.9 of them per unit - the raw figure matches to ~1 %, so `hbm_bytes_per_launch`
+is raw FETCH + WRITE and the x2 figure is kept beside it as `hbm_bytes_per_launch_x2_streaming_rule`.
 """
 import csv
 import glob
@@ -15,6 +18,7 @@ import sys
 
 def main():
     out, match = sys.argv[1], sys.argv[2]
+    known_read = float(sys.argv[3]) if len(sys.argv) > 3 else None
     per = {}
     for path in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         acc = {}
@@ -36,8 +40,16 @@ def main():
                     dur = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "pct": float(row["Percentage"])}
     res = {"kernel_match": match, "counters_per_launch": per, "kernel_trace": dur}
     if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
-        res["hbm_bytes_per_launch_raw"] = (per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
-        res["hbm_bytes_per_launch"] = (2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
+        raw = (per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
+        x2 = (2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
+        res["hbm_bytes_per_launch_x2_streaming_rule"] = x2
+        res["hbm_bytes_per_launch"] = raw
+        if known_read:
+            f = per["FETCH_SIZE"] * 1024
+            res["fetch_calibration"] = {"known_read_bytes": known_read, "fetch_size_bytes": f, "ratio_raw": f / known_read, "ratio_x2": 2 * f / known_read,
+                                        "rule": "raw" if abs(f / known_read - 1) < abs(2 * f / known_read - 1) else "x2"}
+            if res["fetch_calibration"]["rule"] == "x2":
+                res["hbm_bytes_per_launch"] = x2
     if "TCC_HIT_sum" in per:
         res["l2_hit_rate"] = per["TCC_HIT_sum"] / max(1.0, per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
     print(json.dumps(res, indent=1))

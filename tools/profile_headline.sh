@@ -17,7 +17,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU S
   echo "[pmc] $grp"
   timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$tag" -- python3 $ARGS > "$OUT/pmc_$tag.log" 2>&1
 done
-python3 tools/pmc_summarize.py "$OUT" "${KERNEL_MATCH:-k256_mul_fast_kernel}" > gpurun_out/pmc_summary.json
+# known read volume of the headline kernel: 2^24 units x (61.9 table blocks of 64 B + 96 B of input)
+python3 tools/pmc_summarize.py "$OUT" "${KERNEL_MATCH:-k256_mul_fast_kernel}" "${KNOWN_READ_BYTES:-68073553920}" > gpurun_out/pmc_summary.json
 cat gpurun_out/pmc_summary.json
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" gpurun_out/headline_kernel_stats.csv
 # constant-time evidence: per-dispatch instruction counters of the reference schedules on three very different scalar sets
