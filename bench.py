@@ -73,7 +73,9 @@ WORK = {
     "k256_msm": (16.6 * 8 + 1 + 4, 16.6 * 2 + 1),
     # verification = u2 Q (headline kernel) + u1 G (20-bit table) + prep / check (57 scalar-field equivalents + 7)
     "k256_ecdsa_verify": (87 + 128 * 3 + 66 * 15 / 16 * 8 + 9 + 12 * 8 + 6 + 64, 29 + 128 * 4 + 66 * 15 / 16 * 3 + 9 + 12 * 3 + 5),
-    "p256_ecdsa_verify": (64 * 4 * 4 + 61 * 11 + 49 + 6 + 12 * 8 + 6 + 64 + 700, 64 * 4 * 4 + 61 * 5 + 31 + 33 + 12 * 3 + 5),
+    # p256 verification = u2 Q (vb::mul_kernel<CurveP256,8,4>: 256 doublings 4M+4S, 60 general additions 11M+5S, table 4 dbl + 3 add,
+    # output normalise 6M+1S + (255S+12M)/8 = 1 740 M + 1 388 S) + u1 G (20-bit table: 102 M + 41 S) + prep / check (~64 M)
+    "p256_ecdsa_verify": (1740 + 102 + 64, 1388 + 41),
 }
 
 WORKLOADS = {

@@ -639,7 +639,9 @@ static int msm_run(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size
   const size_t sz_aff = (pt_fmt == FMT_PROJECTIVE) ? al(m * 8 * NW) : 0, sz_prep = al((size_t)NHALF * m * 8 * NW);
   const size_t sz_off = al((nb + 1) * 4), sz_coff = al((size_t)(NCB + 1) * 4), sz_tot = al((size_t)NCB * 4), sz_sorted = al((size_t)NDIG * m * 4 + 32);
   // level A of the sort: one 1024-thread workgroup per CU, the chunks of a window side by side
-  const int nch = (c->num_cus - 1) / NWIN > 0 ? (c->num_cus - 1) / NWIN : 1;
+  // (ECGPU_MSM_CHUNK_WGS workgroups per CU, default 1: measurements)
+  static const int chunk_wgs = [] { const char* e = getenv("ECGPU_MSM_CHUNK_WGS"); int v = e ? atoi(e) : 1; return (v < 1 || v > 8) ? 1 : v; }();
+  const int nch = (chunk_wgs * c->num_cus - 1) / NWIN > 0 ? (chunk_wgs * c->num_cus - 1) / NWIN : 1;
   const size_t sz_part = al((size_t)NWIN * nch * NCOARSE * 4);
   const size_t ms = (m + 3) & ~(size_t)3;              // row stride of the digit arrays: four terms per load
   const size_t sz_mag = al((size_t)NDIG * ms * 2), sz_sgn = al(ms * 4);

@@ -343,6 +343,7 @@ def test_two_term_lincomb_throughput_schedule(ctx, cn, cid):
     """LinearCombination::lincomb (k P + l Q, primeorder/src/projective.rs:415-420) on the throughput schedule: the two
     terms share the doublings (varbase_lane.hpp, NT = 2).  4 097 units - several slots per lane only above 2^18, covered by
     the host twin - with edge cases, against the C oracle's two reference multiplications and complete addition."""
+    import ecgpu
     c = M.CURVES[cn]
     nb = c.nbytes
     cv = ctx.curve(cn)

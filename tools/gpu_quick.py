@@ -71,7 +71,7 @@ if mode == "ecdsa":
     sys.exit(0)
 if mode == "msm":
     cv.synth_points_device(d_p, n, synth.SEED); ctx.synchronize()
-    d_r = torch.empty((64,), dtype=torch.uint8, device="cuda")
+    d_r = torch.empty((2 * nb,), dtype=torch.uint8, device="cuda")
     for rep in range(4):
         ctx.timer_start()
         cv.msm_device(d_s, d_p, n, d_r)
