@@ -579,15 +579,20 @@ def main():
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     ctx = ecgpu.Context(local_rank)
-    stream = torch.cuda.current_stream()
+    # One explicit stream for everything: torch's default stream has handle 0, which the C ABI reads as "the context's own
+    # stream" - a different, non-blocking stream that torch (and RCCL, which orders a collective against torch's CURRENT
+    # stream) would not be ordered with.  All device work of this script runs under `with torch.cuda.stream(stream)`.
+    stream = torch.cuda.Stream(device=local_rank)
     ctx.set_stream(stream.cuda_stream)
     env = {"torch": torch, "ecgpu": ecgpu, "ctx": ctx, "dev": torch.device("cuda", local_rank), "rank": rank, "world": world, "dist": dist,
            "backend": args.backend}
 
-    res = run_workload(env, args.workload, args.log2n, args.steps, args.warmup, args.schedule, cpu)
-    other_res = []
-    for o in others:
-        other_res.append(run_workload(env, o, WORKLOADS[o]["log2n"], max(2, min(args.steps, 5)), 1, "fast", cpu_others.get(o)))
+    with torch.cuda.stream(stream):
+        res = run_workload(env, args.workload, args.log2n, args.steps, args.warmup, args.schedule, cpu)
+        other_res = []
+        for o in others:
+            other_res.append(run_workload(env, o, WORKLOADS[o]["log2n"], max(2, min(args.steps, 5)), 1, "fast", cpu_others.get(o)))
+    torch.cuda.synchronize()
     peak_meas, pair_meas = measure_peak(local_rank) if rank == 0 else (None, None)
 
     ok = res["parity"] and all(r["parity"] for r in other_res)

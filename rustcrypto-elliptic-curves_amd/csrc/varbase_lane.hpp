@@ -35,16 +35,17 @@ struct LaneWs {
 // The BATCH tables of a pass are built first and brought to affine form with ONE inversion (Montgomery's trick over
 // BATCH * 8 denominators, 7 multiplications per entry), so that every addition of the main loop is a mixed one
 // (8M + 3S instead of 11M + 5S).
-// Measured: +6 % for P-384, -1.4 % for P-256 (whose multiplication is cheap enough that the extra pass over the
-// tables costs what the cheaper additions save), hence the switch.
-template <class C, int BATCH, int NT = 1>
+// Measured against Jacobian tables with general additions: +8.5 % for P-384 (16.6 against 15.3 M/s at 2^21), +3.7 % for
+// P-256 (53.2 against 51.3; in round 1, with a square-and-multiply inversion of 384 multiplications instead of the
+// 267-multiplication chain, the extra pass over the tables cost P-256 more than the cheaper additions saved).
+template <class C, int BATCH, int NT = 1, int AFFINE = -1>
 ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf, size_t n, size_t base,
                         size_t T, LaneWs<C, BATCH>& ws) {
   static_assert(BATCH % NT == 0 && BATCH <= 32, "table slots per pass");
   constexpr int NW = C::NW;
   constexpr int UB = BATCH / NT;               // units per pass
   using Fe = typename C::Fe;
-  constexpr bool AFFINE_TABLES = (C::NW > 8);
+  constexpr bool AFFINE_TABLES = (AFFINE != 0);      // AFFINE = 0: Jacobian tables and general additions (kept for measurements)
   Jac<C> res[UB];
   Fe pre[UB];
   const int pw = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * NW;

@@ -63,3 +63,24 @@ def test_product_does_not_reference_oracle():
                     for ln in f:
                         code = ln.split("//")[0].split("#")[0] if not fn.endswith(".py") else ln.split("#")[0]
                         assert "oracle/" not in code and "import oracle" not in code and "from oracle" not in code, (fn, ln)
+
+
+def _example_binary():
+    import subprocess
+    d = os.path.join(ROOT, "examples")
+    if not os.path.exists(ecgpu.LIB_PATH):
+        pytest.skip("libecgpu.so not built")
+    subprocess.run(["make", "-s", "-C", d], check=True)
+    return os.path.join(d, "abi_example")
+
+
+def test_c_caller_links_and_fails_loudly_without_gpu():
+    """examples/abi_example.c is a plain-C caller of include/ecgpu.h (gcc, no HIP headers): it must compile and link
+    against the library, and without a gfx950 device stop with the no-device status instead of computing anything."""
+    import subprocess
+    import torch
+    exe = _example_binary()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present (test_gpu_api.py runs the example)")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "no usable gfx950 device" in r.stderr

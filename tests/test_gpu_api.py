@@ -203,3 +203,16 @@ def test_signing_schedules_agree_and_ecdh(cn, cid):
     want = CO.lincomb_batch(cid, k[:100], q[:100], threads=4)
     assert bytes(shared[:100]) == bytes(np.ascontiguousarray(want[:, :cv.nb]))
     ctx.close()
+
+
+def test_plain_c_caller():
+    """The boundary from C, without Python in the data path: examples/abi_example.c (generator multiples, complete
+    addition, point equality, sign + verify) exits 0."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    d = os.path.join(ROOT, "examples")
+    subprocess.run(["make", "-s", "-C", d], check=True)
+    r = subprocess.run([os.path.join(d, "abi_example")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi example ok" in r.stdout and "2 G x = c6047f9441ed7d6d3045406e95c07cd85c778e4b8cef3ca7abac09b95c709ee5" in r.stdout
