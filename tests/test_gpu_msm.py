@@ -231,3 +231,39 @@ def test_nist_msm(cn, cid, path):
         ctx.close()
     finally:
         os.environ.pop("ECGPU_MSM_SMALL", None)
+
+
+@pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1)])
+def test_bucket_path_agrees_with_term_by_term_path_on_awkward_sizes(cn, cid):
+    """Two independent routes to the same sum - the bucket method (digits, two-level sort, bucket parts, reduction tree)
+    and n scalar multiplications folded by a tree - on sizes around the wave, workgroup, chunk-alignment (multiples of
+    four) and slab boundaries, with duplicate points, identity points, zero scalars and repeated scalars mixed in."""
+    import os
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cn)
+    nmax = 131075
+    s_all = CO.synth_scalars(cid, nmax, synth.SEED, 4040)
+    p_all = CO.synth_points(cid, nmax, synth.SEED, 4040)
+    p_all[3] = 0
+    p_all[70] = p_all[69]
+    s_all[70] = s_all[69]
+    s_all[100] = 0
+    s_all[1000:1400] = s_all[999]               # a run of equal scalars: one bucket per window gets 400 extra entries
+    p_all[5000] = 0
+    try:
+        for n in (1, 2, 3, 5, 63, 64, 65, 255, 257, 1023, 1025, 4093, 4095, 4097, 32767, 65537, 131071, 131075):
+            s, p = s_all[:n], p_all[:n]
+            os.environ.pop("ECGPU_MSM_SMALL", None)
+            os.environ.pop("ECGPU_MSM_SLAB", None)
+            a = bytes(cv.msm(s, p))
+            os.environ["ECGPU_MSM_SMALL"] = "0"
+            b = bytes(cv.msm(s, p))
+            assert a == b, n
+            if n > 5000:
+                os.environ["ECGPU_MSM_SLAB"] = "4099"      # ragged slabs (not a multiple of four)
+                assert bytes(cv.msm(s, p)) == a, ("slabs", n)
+    finally:
+        os.environ.pop("ECGPU_MSM_SMALL", None)
+        os.environ.pop("ECGPU_MSM_SLAB", None)
+        ctx.close()
