@@ -89,7 +89,7 @@ WORKLOADS = {
                          bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,4>", pmc_match="vb::mul_kernel",
                          desc="p384 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
     "k256_msm": dict(curve="k256", cid=0, log2n=23, fixed=False, msm=True, metric="k256 MSM points/sec", unit="points/s",
-                     bytes_per_unit=32 + 64, kernel="msm pipeline (digits / sort / bucket sums / reduce)", pmc_match="msm::",
+                     bytes_per_unit=32 + 64, kernel="msm pipeline (digits / sort / bucket sums / reduce)", pmc_match="bucket_sum_kernel",
                      desc="k256 multi-scalar multiplication, 2^%d terms per GPU (one sum; ranks exchange one point each), affine output"),
     "k256_ecdsa_verify": dict(curve="k256", cid=0, log2n=22, fixed=False, msm=False, ecdsa=True, metric="k256 ECDSA verifications/sec", unit="verifications/s",
                               bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + k256_mul_fast_kernel<32,4> + verify_check", pmc_match="k256_mul_fast_kernel",
@@ -304,7 +304,7 @@ def pmc_summary(match, log2n, default_size):
         except Exception:
             continue
         for ent in (js if isinstance(js, list) else [js]):
-            if ent.get("kernel_match") and ent["kernel_match"] in match:
+            if ent.get("kernel_match") and (ent["kernel_match"] in match or match in ent["kernel_match"]):
                 return ent
     return {}
 
@@ -491,9 +491,10 @@ def roofline_for(name, res, schedule, peak_meas, pair_meas):
     if "SQ_ACTIVE_INST_VALU" in ctr and "GRBM_GUI_ACTIVE" in ctr:
         # gfx94x formula of the derived metric (the guide: gfx950 falls back to it): busy VALU cycles over SIMD cycles;
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_ACTIVE_INST_VALU counts quad-cycles over all 1024 SIMDs
+        # (the formula prices every VALU instruction at 4 cycles; moves and plain adds issue faster on gfx950, so a kernel that
+        # never leaves the VALU can read a few per cent above 100: `valu_cycles_per_inst` is the measured average)
         valu_busy = 100.0 * ctr["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (ctr["GRBM_GUI_ACTIVE"] / 8)
-    if "VALUBusy" in ctr:
-        valu_busy = ctr["VALUBusy"]
+    valu_cpi = (ctr["GRBM_GUI_ACTIVE"] / 8 * 1024 / ctr["SQ_INSTS_VALU"]) if ("SQ_INSTS_VALU" in ctr and "GRBM_GUI_ACTIVE" in ctr) else None
     alg_bytes = n * wl["bytes_per_unit"]
     r = {
         "bound": "valu", "achieved": achieved, "peak": PEAK_TMACS, "unit": "TMAC/s (32x32+64 v_mad_u64_u32)", "frac": achieved / PEAK_TMACS,
@@ -503,7 +504,7 @@ def roofline_for(name, res, schedule, peak_meas, pair_meas):
         "achieved_issued": issued, "frac_issued": issued / PEAK_TMACS,
         "peak_measured": peak_meas, "frac_of_peak_measured": (achieved / peak_meas if peak_meas else None),
         "mac_pair_peak_measured": pair_meas, "frac_of_mac_pair_peak": (issued / pair_meas if pair_meas else None),
-        "valu_busy_pct": valu_busy,
+        "valu_busy_pct": valu_busy, "valu_cycles_per_inst": valu_cpi,
         "valu_insts_per_launch": ctr.get("SQ_INSTS_VALU"),
         "hbm": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": alg_bytes / kernel_s / 1e9 / PEAK_HBM_GBS, "bytes_per_unit": wl["bytes_per_unit"]},
