@@ -317,6 +317,7 @@ def run_workload(env, name, log2n, steps, warmup, schedule, cpu):
     rank, world, dist, backend = env["rank"], env["world"], env["dist"], env["backend"]
     from oracle import coracle as CO
     from oracle import ecmodel as M
+    from ecgpu import parallel
     wl = WORKLOADS[name]
     n = 1 << log2n
     cv = ctx.curve(wl["curve"])
@@ -365,14 +366,8 @@ def run_workload(env, name, log2n, steps, warmup, schedule, cpu):
                 # every rank sums its slice; one projective point per rank is all-gathered (96 bytes each; elliptic-curve
                 # addition is not an RCCL reduction operator) and the world's points are folded on the device
                 cv.msm_device(d_s, d_p, n, d_part, out_format=ecgpu.PROJECTIVE)
-                if backend == "nccl":
-                    dist.all_gather_into_tensor(d_all, d_part)
-                else:                                    # gloo rehearsal on one card: the collective runs on host tensors
-                    ctx.synchronize()
-                    h = d_part.cpu()
-                    parts = [torch.empty_like(h) for _ in range(world)]
-                    dist.all_gather(parts, h)
-                    d_all.copy_(torch.stack(parts).to(dev))
+                parallel.allgather_into(d_all, d_part, backend, synchronize=ctx.synchronize)
+                if backend != "nccl":
                     torch.cuda.synchronize()
                 cv.msm_device(d_ones, d_all, world, d_o, point_format=ecgpu.PROJECTIVE)
         else:

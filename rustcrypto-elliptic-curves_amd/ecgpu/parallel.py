@@ -35,6 +35,27 @@ def allgather_points(local_xyz: np.ndarray, group=None) -> np.ndarray:
     return np.stack([o.cpu().numpy() for o in out])
 
 
+def allgather_into(all_parts, part, backend: str, group=None, synchronize=None):
+    """All-gather one projective point per rank into `all_parts` ((world, 3*NB) uint8 tensor) from `part` ((3*NB,) uint8).
+
+    backend "nccl" (RCCL): both tensors live in HBM, the collective is ordered on torch's current stream - no host
+    round trip.  Any other backend (gloo: CPU tests, several ranks rehearsed on one card) moves the 96 bytes through
+    host tensors; `synchronize` (e.g. Context.synchronize) is called first so that the partial sum is complete."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if backend == "nccl":
+        dist.all_gather_into_tensor(all_parts, part, group=group)
+        return all_parts
+    if synchronize is not None:
+        synchronize()
+    h = part.cpu()
+    parts = [torch.empty_like(h) for _ in range(world)]
+    dist.all_gather(parts, h, group=group)
+    all_parts.copy_(torch.stack(parts).to(all_parts.device))
+    return all_parts
+
+
 def msm_sharded(local_msm: Callable[[int, int], np.ndarray], add_points: Callable[[np.ndarray, np.ndarray], np.ndarray],
                 n: int, group=None) -> np.ndarray:
     """sum_i k_i P_i over n terms split across the ranks of `group`.

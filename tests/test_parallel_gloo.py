@@ -43,6 +43,17 @@ def _worker(rank, world, port, n, q):
 
     res = parallel.msm_sharded(local_msm, add_points, n)
     lo, hi = parallel.shard_range(n, rank, world)
+    # the tensor form bench.py uses (here over gloo with host tensors): every rank ends up with all the partial sums
+    import torch
+    part = torch.from_numpy(local_msm(lo, hi).copy())
+    allp = torch.zeros((world, 96), dtype=torch.uint8)
+    called = []
+    parallel.allgather_into(allp, part, "gloo", synchronize=lambda: called.append(1))
+    assert called == [1] and bytes(allp[rank].numpy()) == bytes(part.numpy())
+    acc = allp[0].numpy()
+    for r in range(1, world):
+        acc = add_points(acc, allp[r].numpy())
+    assert bytes(acc) == bytes(res)
     q.put((rank, lo, hi, bytes(res)))
     dist.barrier()
     dist.destroy_process_group()
