@@ -90,6 +90,12 @@ struct ecgpu_curve_ops {
   int (*ecdsa_sign)(ecgpu_ctx* c, const uint32_t* d, const uint32_t* k, const uint32_t* z, uint32_t* sig, uint8_t* recid, uint8_t* ok,
                     size_t n, unsigned flags);
 };
+// Pippenger MSM, one translation unit per curve (msm_*.hip); `mul` is the curve's batch scalar multiplication (affine in / out
+// on device memory), used for small sums
+typedef int (*ecgpu_msm_mul_fn)(ecgpu_ctx* c, const uint32_t* scalars, const uint32_t* points, int pt_fmt, uint32_t* out_xy, size_t n);
+int ecgpu_msm_k256(ecgpu_ctx* c, const uint32_t* sc, const uint32_t* pts, int pt_fmt, size_t n, uint32_t* out, int out_fmt, ecgpu_msm_mul_fn mul);
+int ecgpu_msm_p256(ecgpu_ctx* c, const uint32_t* sc, const uint32_t* pts, int pt_fmt, size_t n, uint32_t* out, int out_fmt, ecgpu_msm_mul_fn mul);
+int ecgpu_msm_p384(ecgpu_ctx* c, const uint32_t* sc, const uint32_t* pts, int pt_fmt, size_t n, uint32_t* out, int out_fmt, ecgpu_msm_mul_fn mul);
 const ecgpu_curve_ops* ecgpu_ops_k256();
 const ecgpu_curve_ops* ecgpu_ops_p256();
 const ecgpu_curve_ops* ecgpu_ops_p384();

@@ -1,6 +1,5 @@
 // secp256k1 kernels and launchers (one translation unit per curve: the library builds in parallel).
 #include "curve_ops.hpp"
-#include "msm_kernels.hpp"
 using namespace ecgpu;
 #ifndef K256_FAST_BATCH
 #define K256_FAST_BATCH 32   // results per lane that share one inversion in the variable-base kernel (16: -0.4 %)
@@ -35,11 +34,12 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
   HIPCHK(c, hipGetLastError());
   return 1;
 }
-// Pippenger MSM (msm.hpp, msm_kernels.hpp)
+// Pippenger MSM (msm.hpp, msm_kernels.hpp; instantiated in msm_k256.hip)
+static int k256_mul_for_msm(ecgpu_ctx* c, const u32* s, const u32* p, int fmt, u32* prod, size_t cnt) {
+  return CurveOps<CurveK256>::lincomb(c, s, p, fmt, 1, prod, FMT_AFFINE, nullptr, cnt, 0);
+}
 template <>
 int CurveOps<CurveK256>::msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt) {
-  return msm::msm_run<CurveK256>(c, sc, pts, pt_fmt, n, out, out_fmt, [&](const u32* s, const u32* p, int fmt, u32* prod, size_t cnt) {
-    return lincomb(c, s, p, fmt, 1, prod, FMT_AFFINE, nullptr, cnt, 0);
-  });
+  return ecgpu_msm_k256(c, sc, pts, pt_fmt, n, out, out_fmt, k256_mul_for_msm);
 }
 const ecgpu_curve_ops* ecgpu_ops_k256() { return CurveOps<CurveK256>::table(); }
