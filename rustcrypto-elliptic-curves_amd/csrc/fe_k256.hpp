@@ -238,6 +238,14 @@ ECGPU_HD bool is_zero(const FeK256& a) {
   const bool is_p = (o == 0xFFFFFFFFu) && (a.v[1] == 0xFFFFFFFEu) && (a.v[0] == (0u - C_LO));
   return z == 0 || is_p;
 }
+// The same test for the throughput schedules' exceptional-case branches (accumulator at infinity, equal or opposite
+// points), taken once or twice per point addition and almost never true: a value that is 0 or p has a top word of 0 or
+// 2^32 - 1, so anything else (probability 1 - 2^-31 on the values these tests see) is rejected after two instructions.
+// Not for the constant-time schedule: which path runs depends on the value.
+ECGPU_HD bool is_zero_fast(const FeK256& a) {
+  if (__builtin_expect(a.v[7] + 1u > 1u, 1)) return false;
+  return is_zero(a);
+}
 ECGPU_HD bool equal(const FeK256& a, const FeK256& b) {
   FeK256 d;
   sub(d, a, b);

@@ -251,6 +251,11 @@ ECGPU_HD void half(FeMont<M>& r, const FeMont<M>& a) {
   r.v[N - 1] = (t[N - 1] >> 1) | (c << 31);
 }
 template <class M> ECGPU_HD bool is_zero(const FeMont<M>& a) { return mp_is_zero<M::N>(a.v); }
+// top-word prefilter for the exceptional-case branches of the throughput schedules (see k256::is_zero_fast)
+template <class M> ECGPU_HD bool is_zero_fast(const FeMont<M>& a) {
+  if (__builtin_expect(a.v[M::N - 1] != 0, 1)) return false;
+  return mp_is_zero<M::N>(a.v);
+}
 template <class M> ECGPU_HD bool equal(const FeMont<M>& a, const FeMont<M>& b) { return mp_eq<M::N>(a.v, b.v); }
 template <class M> ECGPU_HD void select(FeMont<M>& r, bool c, const FeMont<M>& a, const FeMont<M>& b) { mp_select<M::N>(r.v, c, a.v, b.v); }
 

@@ -71,7 +71,7 @@ ECGPU_HD void dbl(Jac<C>& p) {
 template <class C>
 ECGPU_HD void add_mixed(Jac<C>& p, const typename C::Fe& x2, const typename C::Fe& y2) {
   using Fe = typename C::Fe;
-  if (C::fe_is_zero(p.z)) {
+  if (C::fe_is_zero_fast(p.z)) {
     p.x = x2; p.y = y2; C::fe_one(p.z);
     return;
   }
@@ -81,7 +81,7 @@ ECGPU_HD void add_mixed(Jac<C>& p, const typename C::Fe& x2, const typename C::F
   C::fe_mul(t, p.z, t); C::fe_mul(r, t, y2);
   C::fe_sub(h, h, p.x);
   C::fe_sub(r, r, p.y);
-  if (__builtin_expect(C::fe_is_zero(h), 0)) {
+  if (__builtin_expect(C::fe_is_zero_fast(h), 0)) {
     if (C::fe_is_zero(r)) {               // same point
       p.x = x2; p.y = y2; C::fe_one(p.z);
       dbl<C>(p);
@@ -105,8 +105,8 @@ ECGPU_HD void add_mixed(Jac<C>& p, const typename C::Fe& x2, const typename C::F
 template <class C>
 ECGPU_HD void add(Jac<C>& r, const Jac<C>& p, const Jac<C>& q) {
   using Fe = typename C::Fe;
-  if (C::fe_is_zero(p.z)) { r = q; return; }
-  if (C::fe_is_zero(q.z)) { r = p; return; }
+  if (C::fe_is_zero_fast(p.z)) { r = q; return; }
+  if (C::fe_is_zero_fast(q.z)) { r = p; return; }
   Fe z1z1, z2z2, u1, u2, s1, s2, h, rr, t;
   C::fe_sqr(z1z1, p.z); C::fe_sqr(z2z2, q.z);
   C::fe_mul(u1, p.x, z2z2); C::fe_mul(u2, q.x, z1z1);
@@ -114,7 +114,7 @@ ECGPU_HD void add(Jac<C>& r, const Jac<C>& p, const Jac<C>& q) {
   C::fe_mul(t, p.z, z1z1); C::fe_mul(s2, q.y, t);
   C::fe_sub(h, u2, u1);
   C::fe_sub(rr, s2, s1);
-  if (C::fe_is_zero(h)) {
+  if (C::fe_is_zero_fast(h)) {
     if (C::fe_is_zero(rr)) { r = p; dbl<C>(r); return; }
     set_infinity<C>(r);
     return;

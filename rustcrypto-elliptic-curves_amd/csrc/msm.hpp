@@ -72,14 +72,14 @@ ECGPU_HD void xyzz_set_infinity(Xyzz<C>& p) { C::fe_zero(p.x); C::fe_zero(p.y); 
 template <class C>
 ECGPU_HD void xyzz_add_mixed(Xyzz<C>& p, const typename C::Fe& x2, const typename C::Fe& y2) {
   using Fe = typename C::Fe;
-  if (C::fe_is_zero(p.zz)) {
+  if (C::fe_is_zero_fast(p.zz)) {
     p.x = x2; p.y = y2; C::fe_one(p.zz); C::fe_one(p.zzz);
     return;
   }
   Fe pp, r, t, q;
   C::fe_mul(pp, x2, p.zz); C::fe_sub(pp, pp, p.x);           // P = U2 - X1
   C::fe_mul(r, y2, p.zzz); C::fe_sub(r, r, p.y);             // R = S2 - Y1
-  if (__builtin_expect(C::fe_is_zero(pp), 0)) {
+  if (__builtin_expect(C::fe_is_zero_fast(pp), 0)) {
     if (C::fe_is_zero(r)) {                       // same point: 2 (x2, y2), brought from Jacobian (X, Y, Z) to (X, Y, Z^2, Z^3)
       Jac<C> d;
       d.x = x2; d.y = y2; C::fe_one(d.z);

@@ -306,9 +306,12 @@ __device__ __forceinline__ void bucket_add_raw(Xyzz<C>& acc, const RawPoint<C>& 
     x.v[4 * q] = r.v[q].x; x.v[4 * q + 1] = r.v[q].y; x.v[4 * q + 2] = r.v[q].z; x.v[4 * q + 3] = r.v[q].w;
     y.v[4 * q] = r.v[NW / 4 + q].x; y.v[4 * q + 1] = r.v[NW / 4 + q].y; y.v[4 * q + 2] = r.v[NW / 4 + q].z; y.v[4 * q + 3] = r.v[NW / 4 + q].w;
   }
+  // the identity (all zero) contributes nothing; a non-identity point has x.v[NW-1] = y.v[NW-1] = 0 with probability 2^-64
+  if (__builtin_expect((x.v[NW - 1] | y.v[NW - 1]) == 0, 0)) {
 #pragma unroll
-  for (int q = 0; q < NW; q++) z |= x.v[q] | y.v[q];
-  if (z == 0) return;                          // the identity (all zero) contributes nothing
+    for (int q = 0; q < NW; q++) z |= x.v[q] | y.v[q];
+    if (z == 0) return;
+  }
   if (e >> 31) C::fe_neg(y, y);
   xyzz_add_mixed<C>(acc, x, y);
 }

@@ -65,7 +65,7 @@ ECGPU_HD void jac_double_affine(JacK256& r, const FeK256& x, const FeK256& y) {
 //   same x, same y (H=R=0)   -> doubling of (x2, y2)
 //   same x, opposite y       -> Z3 = Z1 * 0 = 0: infinity falls out of the formula
 ECGPU_HD void jac_add_mixed(JacK256& p, const FeK256& x2, const FeK256& y2, FeK256* zr) {
-  if (is_zero(p.z)) {
+  if (is_zero_fast(p.z)) {
     p.x = x2; p.y = y2; set_one(p.z);
     if (zr) set_one(*zr);
     return;
@@ -76,7 +76,7 @@ ECGPU_HD void jac_add_mixed(JacK256& p, const FeK256& x2, const FeK256& y2, FeK2
   mul(t, p.z, t); mul(r, t, y2);             // S2
   sub(h, h, p.x);                            // H
   sub(r, r, p.y);                            // R
-  if (__builtin_expect(is_zero(h) && is_zero(r), 0)) {   // never taken for honest GLV digits; kept exact
+  if (__builtin_expect(is_zero_fast(h) && is_zero(r), 0)) {   // never taken for honest GLV digits; kept exact
     if (zr) dbl(*zr, y2);
     jac_double_affine(p, x2, y2);
     return;

@@ -40,6 +40,7 @@ struct CurveK256 {
   static ECGPU_HD void fe_inv(Fe& r, const Fe& a) { k256::inv(r, a); }
   static ECGPU_HD bool fe_sqrt(Fe& r, const Fe& a) { return k256::sqrt(r, a); }
   static ECGPU_HD bool fe_is_zero(const Fe& a) { return k256::is_zero(a); }
+  static ECGPU_HD bool fe_is_zero_fast(const Fe& a) { return k256::is_zero_fast(a); }
   static ECGPU_HD bool fe_is_odd(const Fe& a) { return k256::is_odd(a); }
   static ECGPU_HD void fe_zero(Fe& r) { k256::set_zero(r); }
   static ECGPU_HD void fe_one(Fe& r) { k256::set_one(r); }
@@ -98,6 +99,7 @@ struct CurveNist {
   static ECGPU_HD void fe_inv(Fe& r, const Fe& a) { mont::inv(r, a); }
   static ECGPU_HD bool fe_sqrt(Fe& r, const Fe& a) { return mont::sqrt(r, a); }
   static ECGPU_HD bool fe_is_zero(const Fe& a) { return mont::is_zero(a); }
+  static ECGPU_HD bool fe_is_zero_fast(const Fe& a) { return mont::is_zero_fast(a); }
   static ECGPU_HD bool fe_is_odd(const Fe& a) { u32 c[NW]; mont::from_mont<Mod>(c, a); return c[0] & 1; }   // p256 field.rs:109-112
   static ECGPU_HD void fe_zero(Fe& r) { mont::set_zero(r); }
   static ECGPU_HD void fe_one(Fe& r) { mont::set_one(r); }
