@@ -419,8 +419,10 @@ __global__ void gen_table_kernel(typename C::Pt* tab) {
   if (blockIdx.x == 0 && threadIdx.x == 0) C::gen_table_build(tab);
 }
 
+// (occupancy target: the 12-limb curve needs the same two-waves budget as lincomb_ref_kernel - left alone the allocator takes
+// 280 VGPRs, one wave per SIMD, and P-384's constant-time k G ran 29 % slower than its variable-base twin)
 template <class C>
-__global__ void __launch_bounds__(256) mul_gen_ref_kernel(const u32* scalars, const typename C::Pt* gen_tab, u32* out,
+__global__ void __launch_bounds__(256, (C::NW > 8 ? ECGPU_REF_WAVES : 1)) mul_gen_ref_kernel(const u32* scalars, const typename C::Pt* gen_tab, u32* out,
                                                           int out_fmt, uint8_t* out_inf, size_t n) {
   typename C::Pt tab[C::ID == 0 ? 1 : C::REF_TABLE_PTS];   // scratch for curves whose mul_by_generator is G * k
   ECGPU_GRID_STRIDE(i, n) {

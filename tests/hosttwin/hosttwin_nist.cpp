@@ -144,3 +144,34 @@ extern "C" int ht_xyzz_add_mixed(int curve, const uint8_t* p, const uint8_t* q, 
   if (curve == 0) return xyzz_op<CurveK256>(p, q, out, n);
   return curve == 1 ? xyzz_op<CurveP256>(p, q, out, n) : xyzz_op<CurveP384>(p, q, out, n);
 }
+
+// ---- hash to curve: map_to_curve (count = 1) or the sum of two maps (count = 2), as the kernel does it (h2c_map.hpp) ----
+#include "h2c_map.hpp"
+template <class C>
+static int h2c_map_host(const uint8_t* u, int count, uint8_t* out_xy, uint8_t* out_inf, int n) {
+  for (int i = 0; i < n; i++) {
+    typename C::Fe uu;
+    typename C::Pt p;
+    load<C>(uu, u + (size_t)C::NB * count * i);
+    h2c::map_to_curve<C>(p, uu);
+    if (count == 2) {
+      typename C::Pt q, r;
+      load<C>(uu, u + (size_t)C::NB * (count * i + 1));
+      h2c::map_to_curve<C>(q, uu);
+      C::pt_add(r, p, q);
+      p = r;
+    }
+    typename C::Fe zi, x, y;
+    const bool inf = C::fe_is_zero(p.z);
+    C::fe_inv(zi, p.z);
+    C::fe_mul(x, p.x, zi); C::fe_mul(y, p.y, zi);
+    if (inf) { C::fe_zero(x); C::fe_zero(y); }
+    store<C>(out_xy + 2 * C::NB * i, x); store<C>(out_xy + 2 * C::NB * i + C::NB, y);
+    out_inf[i] = inf ? 1 : 0;
+  }
+  return 0;
+}
+extern "C" int ht_h2c_map(int curve, const uint8_t* u, int count, uint8_t* out_xy, uint8_t* out_inf, int n) {
+  if (curve == 0) return h2c_map_host<CurveK256>(u, count, out_xy, out_inf, n);
+  return curve == 1 ? h2c_map_host<CurveP256>(u, count, out_xy, out_inf, n) : h2c_map_host<CurveP384>(u, count, out_xy, out_inf, n);
+}

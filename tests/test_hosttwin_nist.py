@@ -101,3 +101,46 @@ def test_mul_ref_exact_xyz_and_vectors(cn, cid, ref_vectors):
     for i, (k, x, y) in enumerate(vec):
         X, Y, Z = (int.from_bytes(o[w * i + c.nbytes * t:w * i + c.nbytes * (t + 1)], "big") for t in range(3))
         assert M.to_affine_opt(c, (X, Y, Z)) == (int(x, 16), int(y, 16))
+
+
+@pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1), ("p384", 2)])
+def test_hash_to_curve_map(cn, cid, ref_vectors):
+    """h2c_map.hpp on the host: the RFC 9380 vectors of <curve>/src/arithmetic/hash2curve.rs (u -> Q0, Q1 and Q0 + Q1 = P),
+    then edge and random field elements against the model - the map keeps x as a fraction, evaluates the secp256k1
+    isogeny in homogeneous form and inverts once per output."""
+    import ctypes
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    L = lib()
+    L.ht_h2c_map.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+
+    def run(us, count):
+        n = len(us) // count
+        out, inf = outbuf(2 * nb * n), outbuf(n)
+        assert L.ht_h2c_map(cid, buf(b"".join(M.i2b(c, u) for u in us)), count, out, inf, n) == 0
+        o = bytes(out)
+        return [o[2 * nb * i:2 * nb * (i + 1)] for i in range(n)], bytes(inf)
+
+    vs = ref_vectors[cn]["hash2curve"]
+    us = [int(v[k], 16) for v in vs for k in ("u_0", "u_1")]
+    q, inf = run(us, 1)
+    assert not any(inf)
+    for i, v in enumerate(vs):
+        assert q[2 * i].hex() == v["q0_x"] + v["q0_y"] and q[2 * i + 1].hex() == v["q1_x"] + v["q1_y"]
+    pts, inf = run(us, 2)
+    assert [p.hex() for p in pts] == [v["p_x"] + v["p_y"] for v in vs] and not any(inf)
+    rng = random.Random(9380)
+    us = [0, 1, 2, c.p - 1, c.p - 2] + [rng.randrange(c.p) for _ in range(60)]
+    got, _ = run(us, 1)
+    for x, g in zip(us, got):
+        Q = M.map_to_curve(c, x)
+        assert g == M.i2b(c, Q[0]) + M.i2b(c, Q[1]), x
+    pairs = [(us[i], us[i + 1]) for i in range(0, 40, 2)] + [(7, 7), (9, c.p - 9)]      # equal points; u and -u map to P and -P
+    got, inf = run([u for ab in pairs for u in ab], 2)
+    for (a, b), g, f in zip(pairs, got, inf):
+        S = M.affine_add(c, M.map_to_curve(c, a), M.map_to_curve(c, b))
+        if S is None:
+            assert f == 1 and not g.strip(b"\0")
+        else:
+            assert f == 0 and g == M.i2b(c, S[0]) + M.i2b(c, S[1])
+    assert inf[-1] == 1
