@@ -243,7 +243,9 @@ ECGPU_HD bool is_zero(const FeK256& a) {
 // 2^32 - 1, so anything else (probability 1 - 2^-31 on the values these tests see) is rejected after two instructions.
 // Not for the constant-time schedule: which path runs depends on the value.
 ECGPU_HD bool is_zero_fast(const FeK256& a) {
+#ifndef ECGPU_NO_ZERO_PREFILTER        // A/B switch for measurements
   if (__builtin_expect(a.v[7] + 1u > 1u, 1)) return false;
+#endif
   return is_zero(a);
 }
 ECGPU_HD bool equal(const FeK256& a, const FeK256& b) {

@@ -34,7 +34,8 @@ FIELD_BYTES = {K256: 32, P256: 32, P384: 48}
 FE_MUL, FE_SQR, FE_ADD, FE_SUB, FE_NEG, FE_INV, FE_SQRT = range(7)
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libecgpu.so")
+# ECGPU_LIB: another build of the library (A/B measurements of compile-time switches); default: the in-tree build
+LIB_PATH = os.environ.get("ECGPU_LIB") or os.path.join(_PKG_ROOT, "lib", "libecgpu.so")
 
 
 class EcgpuError(RuntimeError):

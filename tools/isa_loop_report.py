@@ -58,6 +58,16 @@ def main():
         body = [t for _, t in instrs[s:e + 1]]
         print("%8d %8d %7d %8d %6d %7d %7d" % (s, e, e - s + 1, sum(t.startswith("scratch_") for t in body), sum(t.startswith("v_mad_u64_u32") for t in body),
                                             sum(t.startswith("global_load") for t in body), sum(t.startswith("global_store") for t in body)))
+    # where the scratch instructions sit: clusters of instruction indices (gap > 400 starts a new cluster)
+    idx = [i for i, (_, t) in enumerate(instrs) if t.startswith("scratch_")]
+    clusters = []
+    for i in idx:
+        if clusters and i - clusters[-1][1] <= 400:
+            clusters[-1][1] = i
+            clusters[-1][2] += 1
+        else:
+            clusters.append([i, i, 1])
+    print("scratch instruction clusters (first..last index: count): " + ", ".join("%d..%d: %d" % tuple(c) for c in clusters))
 
 
 if __name__ == "__main__":
