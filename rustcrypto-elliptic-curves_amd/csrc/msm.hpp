@@ -5,17 +5,19 @@
 // terms; the primeorder curves only have the two-term default (primeorder/src/projective.rs:415-420).  The result is
 // the same group element; the schedule here is
 //   0. secp256k1: the GLV split of every scalar (decompose_scalar, mul.rs:260-268: k = k1 + k2 lambda, |k1|, |k2| < 2^128),
-//      so a term is two half-terms (k1, P) and (k2, lambda P = (beta x, y)) and there are 8 windows instead of 16: half the
-//      buckets to reduce and 128 instead of 256 doublings in the serial tail, for the same number of bucket additions.
-//      P-256 / P-384 have no such endomorphism: one half, 16 / 24 windows; k > n/2 is replaced by n - k and -P so that the
-//      carry window of the signed recoding stays almost empty.
-//   1. signed c-bit digits of every (half-)scalar, computed once (c = 16, 2^15 buckets per window); the points are brought
-//      to the field's internal form once as well (for the NIST curves that is the conversion to Montgomery form)
-//   2. two-level counting sort of the (half-term, window) entries by bucket (512 coarse bins, then 64 buckets within a
-//      bin; LDS-privatised counters at both levels, msm_kernels.hpp)
-//   3. bucket sums in XYZZ coordinates (mixed addition 8M + 2S), a bucket's run cut into parts for neighbouring lanes;
-//      exceptional cases handled, buckets with very many entries summed by whole workgroups
-//   4. per window sum_j j*B_j by segmented running sums, then Horner over the windows
+//      so a term is two half-terms (k1, P) and (k2, lambda P = (beta x, y)) and the windows cover 128 instead of 256 bits:
+//      half the buckets to reduce and half the doublings in the serial tail, for the same number of bucket additions.
+//      P-256 / P-384 have no such endomorphism: one half; k > n/2 is replaced by n - k and -P so that the top digit stays
+//      below half the window range.
+//   1. signed c-bit digits of every (half-)scalar, computed once; c = 16 (2^15 buckets per window, 8 windows and a
+//      carry window for secp256k1) or c = 19 for large sums (2^18 buckets, 7 windows, no carry window: 18 % fewer bucket
+//      additions).  The points are brought to the field's internal form once as well.
+//   2. two-level counting sort of the (half-term, window) entries by bucket (coarse bins, then the buckets within a bin;
+//      LDS-privatised counters at both levels, msm_kernels.hpp)
+//   3. bucket sums in XYZZ coordinates (mixed addition 8M + 2S) over EQUAL runs of the sorted entries: a lane sums the same
+//      number of consecutive entries whatever buckets they belong to, writes the buckets that end inside its run and leaves
+//      the two it shares with its neighbours as pieces; exceptional cases of the addition handled
+//   4. per window sum_j j*B_j by a tree of running sums, then Horner over the windows
 // Every stage is a kernel over device memory; no host round trips until the final point.
 #pragma once
 #include "jacobian.hpp"
@@ -23,25 +25,6 @@
 
 namespace ecgpu {
 namespace msm {
-
-constexpr int CBITS = 16;                     // window bits
-constexpr int NBUCKET = 1 << (CBITS - 1);     // |digit| in 1..2^15
-// bucket reduction tree: 2^15 buckets = NSEG1 x SEG1 x SEG0 per window.  Short runs keep the dependent chains of the
-// two segment kernels short (16 and 32 additions); the window kernel finishes with LDS tree sums over NSEG1 lanes.
-constexpr int LOG_SEG0 = 3, SEG0 = 1 << LOG_SEG0;     // buckets per level-0 run
-constexpr int LOG_SEG1 = 4, SEG1 = 1 << LOG_SEG1;     // level-0 results per level-1 run
-constexpr int NSEG0 = NBUCKET / SEG0;                 // level-0 runs per window (4096)
-constexpr int LOG_NSEG1 = CBITS - 1 - LOG_SEG0 - LOG_SEG1;
-constexpr int NSEG1 = 1 << LOG_NSEG1;                 // level-1 runs per window (256)
-constexpr int SUMW_LEN = NSEG0 / NSEG1, NSUMW = NSEG1;  // partial sums of the level-0 weighted parts, one per window-kernel lane
-
-// per-curve shape of the digit matrix
-template <class C>
-struct Cfg {
-  static constexpr int NHALF = C::A_IS_ZERO ? 2 : 1;                               // GLV halves per term (secp256k1 only)
-  static constexpr int NWIN = (C::A_IS_ZERO ? 8 : 2 * C::NW) + 1;                  // 16-bit windows of a (half-)scalar + the carry window
-  static constexpr int NDIG = NWIN * NHALF;                                        // digit columns per term
-};
 
 // doubling and general addition on Jacobian triples: secp256k1 keeps its own doubling (funnel-shift small multiples)
 template <class C>
@@ -58,7 +41,7 @@ ECGPU_HD void pt_add(Jac<C>& r, const Jac<C>& p, const Jac<C>& q) { jac::add<C>(
 
 // XYZZ coordinates for the bucket accumulators: x = X / ZZ, y = Y / ZZZ with ZZ^3 = ZZZ^2, infinity <=> ZZ = 0.
 // Adding an affine point costs 8M + 2S (madd-2008-s, independent of the curve coefficients), one squaring less than the
-// Jacobian mixed addition; the 134 M bucket additions of a 2^23-term sum are where that squaring counts.  Buckets leave the
+// Jacobian mixed addition; the 10^8 bucket additions of a 2^23-term sum are where that squaring counts.  Buckets leave the
 // accumulation as Jacobian triples (X ZZ, Y ZZZ, ZZ) - two multiplications - because the reduction tree doubles, and
 // doubling is cheaper there.
 template <class C>
@@ -101,6 +84,13 @@ ECGPU_HD void xyzz_add_mixed(Xyzz<C>& p, const typename C::Fe& x2, const typenam
   C::fe_mul(t, p.y, t);                                      // Y1 PPP
   C::fe_sub(q, q, p.x); C::fe_mul(q, r, q);                  // R (Q - X3)
   C::fe_sub(p.y, q, t);
+}
+// (X, Y, Z) -> (X, Y, Z^2, Z^3): the same point, x = X / Z^2, y = Y / Z^3
+template <class C>
+ECGPU_HD void jacobian_to_xyzz(Xyzz<C>& r, const Jac<C>& p) {
+  r.x = p.x; r.y = p.y;
+  C::fe_sqr(r.zz, p.z);
+  C::fe_mul(r.zzz, r.zz, p.z);
 }
 template <class C>
 ECGPU_HD void xyzz_to_jacobian(Jac<C>& r, const Xyzz<C>& p) {

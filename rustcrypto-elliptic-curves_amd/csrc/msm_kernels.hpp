@@ -1,6 +1,7 @@
-// Kernels and host launcher of the Pippenger MSM (see msm.hpp for the schedule), written once over the curve traits.
-// Device code only.
+// Kernels and host launcher of the Pippenger MSM (see msm.hpp for the schedule), written once over the curve traits and
+// the window width.  Device code only.
 #pragma once
+#include <type_traits>
 #include "ecgpu_internal.hpp"
 #include "kernels.hpp"
 #include "msm.hpp"
@@ -9,64 +10,99 @@ namespace ecgpu {
 namespace msm {
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Geometry of one window width CB (bits of a signed digit): buckets, the two levels of the sort, the sorted entry, the
+// reduction tree.  Two widths are instantiated: 16 (sums below 2^21 terms) and 19.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CB>
+struct Geo {
+  static constexpr int CBITS = CB;
+  static constexpr int NBUCKET = 1 << (CB - 1);              // |digit| in 1 .. 2^(CB-1)
+  // sort: NCOARSE coarse bins of NFINE buckets per window
+  static constexpr int LOG_FINE = (CB <= 16) ? 6 : 7, NFINE = 1 << LOG_FINE, NCOARSE = NBUCKET / NFINE;
+  // sorted entry (32 bits) = term index | low bucket bits << INDEX_BITS | GLV half << 30 | subtract << 31
+  static constexpr int INDEX_BITS = 30 - LOG_FINE;
+  static constexpr u32 INDEX_MASK = (1u << INDEX_BITS) - 1u;
+  static constexpr size_t SLAB_TERMS = (size_t)1 << INDEX_BITS;      // a call is cut into slabs of this many terms
+  // reduction tree: M children per node and level, down to NTOP nodes per window (one workgroup finishes a window)
+  static constexpr int LOG_M = 3, M = 1 << LOG_M, LOG_NTOP = 9, NTOP = 1 << LOG_NTOP;
+  static constexpr int NLEVEL = (CB - 1 - LOG_NTOP) / LOG_M;         // levels including the one that reads the buckets
+  static_assert((CB - 1 - LOG_NTOP) % LOG_M == 0 && NLEVEL >= 1, "the tree must end at NTOP nodes");
+  using Mag = typename std::conditional<(CB <= 16), uint16_t, u32>::type;   // storage of a digit magnitude (0 .. 2^(CB-1))
+};
+// per-curve shape of the digit matrix
+template <class C, int CB>
+struct Cfg {
+  static constexpr int NHALF = C::A_IS_ZERO ? 2 : 1;                 // GLV halves per term (secp256k1 only)
+  static constexpr int BITS = C::A_IS_ZERO ? 128 : 32 * C::NW;       // bits of a (half-)scalar magnitude
+  static constexpr int NREAL = (BITS + CB - 1) / CB;                 // windows that cover them
+  // a window width that divides BITS leaves no room for the carry of the signed recoding: one more window with a single
+  // bucket takes it.  Otherwise the top window holds fewer than CB - 1 bits and its digit stays positive.
+  static constexpr bool HAS_CARRY = (NREAL * CB == BITS);
+  static constexpr int NWIN = NREAL + (HAS_CARRY ? 1 : 0);
+  static constexpr int NDIG = NWIN * NHALF;                          // digit columns per term
+  static_assert(NDIG <= 32, "one sign bit per digit column");
+  static_assert(HAS_CARRY || BITS - (NREAL - 1) * CB <= CB - 1, "the top digit must fit the bucket range without a carry");
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 0. The digits of every term, computed ONCE (the first version re-derived all digits of a term in each of the
 //    histogram and scatter workgroups that looked at it).
 //    secp256k1: the scalar is split by the endomorphism (k = k1 + k2 lambda, magnitudes below 2^128 and two signs); each
-//    half gives 8 signed 16-bit digits in [-2^15, 2^15) and a carry digit in {0, 1} (window 8, a single bucket).
-//    P-256 / P-384: one "half"; k > n/2 is replaced by n - k with the opposite sign (the carry window of the recoding is
-//    then almost always empty; without this half of all terms land in its single bucket).
-//    mag[(NHALF w + h) * ns + i] = |digit| of window w of half h (0 .. 2^15; window-major so that a workgroup streams its
-//    window's digits, four 16-bit words per load; the row stride ns is n rounded up to a multiple of four),
+//    half gives NREAL signed CB-bit digits in [-2^(CB-1), 2^(CB-1)) and, for CB = 16, a carry digit in {0, 1}.
+//    P-256 / P-384: one "half"; k > n/2 is replaced by n - k with the opposite sign.
+//    mag[(NHALF w + h) * ns + i] = |digit| of window w of half h (window-major so that a workgroup streams its window's
+//    digits, four per load; the row stride ns is n rounded up to a multiple of four),
 //    sgn[i] bit NHALF w + h = the entry is subtracted (sign of the digit xor sign of the half).  Terms whose point is the
 //    identity are not filtered here: the bucket sums skip them.
 // ---------------------------------------------------------------------------------------------------------------------
-template <class C>
-__global__ void __launch_bounds__(256) digits_kernel(const u32* scalars, size_t n, size_t ns, uint16_t* mag, u32* sgn) {
-  constexpr int NW = C::NW, NHALF = Cfg<C>::NHALF, NWIN = Cfg<C>::NWIN;
-  static_assert(Cfg<C>::NDIG <= 32, "one sign bit per digit column");
+template <int NWORDS, int CB>
+__device__ __forceinline__ u32 window_bits(const u32* k, int w) {
+  const int bit = w * CB, lo = bit >> 5, sh = bit & 31;
+  u32 v = (lo < NWORDS) ? (k[lo] >> sh) : 0u;
+  if (sh + CB > 32 && lo + 1 < NWORDS) v |= k[lo + 1] << (32 - sh);
+  return v & ((1u << CB) - 1u);
+}
+template <class C, int CB, int NWORDS>
+__device__ __forceinline__ void recode_half(const u32* m, u32 neg, int h, size_t i, size_t ns, typename Geo<CB>::Mag* mag, u32& bits) {
+  using K = Cfg<C, CB>;
+  using Mag = typename Geo<CB>::Mag;
+  constexpr int NHALF = K::NHALF;
+  u32 carry = 0;
+#pragma unroll
+  for (int w = 0; w < K::NREAL; w++) {
+    const u32 v = window_bits<NWORDS, CB>(m, w) + carry;
+    if (w < K::NREAL - 1 || K::HAS_CARRY) carry = (v >= (1u << (CB - 1))) ? 1u : 0u;      // v in [2^(CB-1), 2^CB] becomes v - 2^CB with a carry
+    else carry = 0;                                                                        // top window with spare bits: v <= 2^(CB-1)
+    const int d = (int)v - (int)(carry << CB);
+    mag[(size_t)(NHALF * w + h) * ns + i] = (Mag)(d < 0 ? -d : d);
+    bits |= (((d < 0) ? 1u : 0u) ^ neg) << (NHALF * w + h);
+  }
+  if (K::HAS_CARRY) {
+    mag[(size_t)(NHALF * K::NREAL + h) * ns + i] = (Mag)carry;
+    bits |= neg << (NHALF * K::NREAL + h);
+  }
+}
+template <class C, int CB>
+__global__ void __launch_bounds__(256) digits_kernel(const u32* scalars, size_t n, size_t ns, typename Geo<CB>::Mag* mag, u32* sgn) {
+  constexpr int NW = C::NW;
   ECGPU_GRID_STRIDE(i, n) {
     u32 k[NW], ord[NW];
     C::scalar_load(k, scalars + i * NW);
     C::order(ord);
     reduce_once<NW>(k, ord);
     u32 bits = 0;
-    if constexpr (NHALF == 2) {
+    if constexpr (Cfg<C, CB>::NHALF == 2) {
       k256::GlvSplit sp;
       k256::glv_split(sp, k);
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const u32* m = h ? sp.k2 : sp.k1;
-        const u32 neg = (h ? sp.neg2 : sp.neg1) ? 1u : 0u;
-        u32 carry = 0;
-#pragma unroll
-        for (int w = 0; w < NWIN - 1; w++) {
-          const u32 v = ((m[w >> 1] >> (16 * (w & 1))) & 0xFFFFu) + carry;
-          carry = (v >= 0x8000u) ? 1u : 0u;      // v in [2^15, 2^16] becomes v - 2^16 with a carry
-          const int d = (int)v - (int)(carry << 16);
-          mag[(size_t)(2 * w + h) * ns + i] = (uint16_t)(d < 0 ? -d : d);
-          bits |= (((d < 0) ? 1u : 0u) ^ neg) << (2 * w + h);
-        }
-        mag[(size_t)(2 * (NWIN - 1) + h) * ns + i] = (uint16_t)carry;
-        bits |= neg << (2 * (NWIN - 1) + h);
-      }
+      recode_half<C, CB, 4>(sp.k1, sp.neg1 ? 1u : 0u, 0, i, ns, mag, bits);
+      recode_half<C, CB, 4>(sp.k2, sp.neg2 ? 1u : 0u, 1, i, ns, mag, bits);
     } else {
       u32 t[NW];
       mp_sub<NW>(t, ord, k);                   // n - k
       const bool flip = !mp_geq<NW>(t, k);     // n - k < k
 #pragma unroll
       for (int w = 0; w < NW; w++) k[w] = flip ? t[w] : k[w];
-      const u32 neg = flip ? 1u : 0u;
-      u32 carry = 0;
-#pragma unroll
-      for (int w = 0; w < NWIN - 1; w++) {
-        const u32 v = ((k[w >> 1] >> (16 * (w & 1))) & 0xFFFFu) + carry;
-        carry = (v >= 0x8000u) ? 1u : 0u;
-        const int d = (int)v - (int)(carry << 16);
-        mag[(size_t)w * ns + i] = (uint16_t)(d < 0 ? -d : d);
-        bits |= (((d < 0) ? 1u : 0u) ^ neg) << w;
-      }
-      mag[(size_t)(NWIN - 1) * ns + i] = (uint16_t)carry;
-      bits |= neg << (NWIN - 1);
+      recode_half<C, CB, NW>(k, flip ? 1u : 0u, 0, i, ns, mag, bits);
     }
     sgn[i] = bits;
   }
@@ -91,7 +127,7 @@ __global__ void __launch_bounds__(256) prepare_points_kernel(const u32* xy, u32*
     for (int q = 0; q < NW / 4; q++) dst[q] = make_uint4(x.v[4 * q], x.v[4 * q + 1], x.v[4 * q + 2], x.v[4 * q + 3]);
 #pragma unroll
     for (int q = 0; q < NW / 4; q++) dst[NW / 4 + q] = make_uint4(y.v[4 * q], y.v[4 * q + 1], y.v[4 * q + 2], y.v[4 * q + 3]);
-    if constexpr (Cfg<C>::NHALF == 2) {
+    if constexpr (C::A_IS_ZERO) {
       FeK256 b;
       k256::beta(b);
       k256::mul(x, x, b);
@@ -107,61 +143,63 @@ __global__ void __launch_bounds__(256) prepare_points_kernel(const u32* xy, u32*
 // ---------------------------------------------------------------------------------------------------------------------
 // Two-level counting sort of the (half-term, window) entries by bucket, privatised in LDS.
 //
-// A direct scatter into the 2^15 buckets of a window (the first version) writes every 4-byte entry to a different
-// cache line, and a workgroup comes back to the same line only after it has touched ~32 768 others: the lines leave the
-// L2 partly written, HBM sees 142 M masked partial writes, and the scatter ran at 3.3 ms for 0.57 GB of output.
+// A direct scatter into the buckets of a window (the first version) writes every 4-byte entry to a different cache line,
+// and a workgroup comes back to the same line only after it has touched tens of thousands of others: the lines leave
+// the L2 partly written, HBM sees 142 M masked partial writes, and the scatter ran at 3.3 ms for 0.57 GB of output.
 // Sorting in two levels keeps the set of lines a workgroup is filling small enough for the L2 to merge them:
-//   level A  a workgroup owns one window and one contiguous chunk of the terms and splits its entries into NCOARSE = 512
-//            coarse bins of NFINE = 64 buckets (512 open lines per workgroup);
-//   level B  a workgroup owns one coarse bin (its entries are contiguous after level A) and sorts it by the low six bits
-//            of the bucket number (64 open lines), which also yields the bucket offsets.
-// Every count and every cursor increment is an LDS atomic.  An entry is 32 bits: term index (24 bits, so a call is cut
-// into slabs of 2^24 terms), the low six bucket bits (needed by level B only), the GLV half and the subtract flag.
+//   level A  a workgroup owns one window and one contiguous chunk of the terms and splits its entries into NCOARSE
+//            coarse bins of NFINE buckets;
+//   level B  a workgroup owns one coarse bin (its entries are contiguous after level A) and sorts it by the low bucket
+//            bits, which also yields the bucket offsets.
+// Every count and every cursor increment is an LDS atomic.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int LOG_FINE = 6, NFINE = 1 << LOG_FINE, NCOARSE = NBUCKET / NFINE;
-constexpr size_t SLAB_TERMS = (size_t)1 << 24;
-constexpr u32 ENTRY_INDEX_MASK = 0x00FFFFFFu;          // entry = index | fine << 24 | half << 30 | subtract << 31
 // chunk g of nch: boundaries are multiples of four terms (the loops below take four terms per step), the last chunk ends at n
 __device__ __forceinline__ void chunk_range(size_t n, int g, int nch, size_t& lo, size_t& hi) {
   lo = (n * (size_t)g / nch) & ~(size_t)3;
   hi = (g == nch - 1) ? n : ((n * (size_t)(g + 1) / nch) & ~(size_t)3);
 }
-// the four 16-bit digits at terms i .. i + 3 of one row (i a multiple of four: one 8-byte load)
+// the four digit magnitudes at terms i .. i + 3 of one row (i a multiple of four: one 8- or 16-byte load)
 __device__ __forceinline__ void load_mag4(u32* a, const uint16_t* row, size_t i) {
   const uint2 v = *(const uint2*)(row + i);
   a[0] = v.x & 0xFFFFu; a[1] = v.x >> 16; a[2] = v.y & 0xFFFFu; a[3] = v.y >> 16;
 }
+__device__ __forceinline__ void load_mag4(u32* a, const u32* row, size_t i) {
+  const uint4 v = *(const uint4*)(row + i);
+  a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+}
 // A1. part[w][g][cb] = number of entries of chunk g of window w in coarse bin cb
-static __global__ void __launch_bounds__(1024) coarse_hist_kernel(const uint16_t* mag, size_t n, size_t ns, int nhalf, int nch, u32* part) {
-  __shared__ u32 cnt[NCOARSE];
+template <int CB>
+__global__ void __launch_bounds__(1024) coarse_hist_kernel(const typename Geo<CB>::Mag* mag, size_t n, size_t ns, int nhalf, int nch, u32* part) {
+  using G = Geo<CB>;
+  __shared__ u32 cnt[G::NCOARSE];
   const int w = blockIdx.x / nch, g = blockIdx.x % nch;
-  for (int b = threadIdx.x; b < NCOARSE; b += 1024) cnt[b] = 0;
+  for (int b = threadIdx.x; b < G::NCOARSE; b += 1024) cnt[b] = 0;
   __syncthreads();
   size_t lo, hi;
   chunk_range(n, g, nch, lo, hi);
 #pragma unroll 1
   for (int h = 0; h < nhalf; h++) {
-    const uint16_t* src = mag + (size_t)(nhalf * w + h) * ns;
+    const typename G::Mag* src = mag + (size_t)(nhalf * w + h) * ns;
     for (size_t i = lo + 4 * (size_t)threadIdx.x; i < hi; i += 4096) {       // the row is padded to ns: reading past n within it is safe
       u32 a[4];
       load_mag4(a, src, i);
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        if (a[q] && i + q < hi) atomicAdd(&cnt[(a[q] - 1) >> LOG_FINE], 1u);
+        if (a[q] && i + q < hi) atomicAdd(&cnt[(a[q] - 1) >> G::LOG_FINE], 1u);
     }
   }
   __syncthreads();
-  u32* dst = part + ((size_t)w * nch + g) * NCOARSE;
-  for (int b = threadIdx.x; b < NCOARSE; b += 1024) dst[b] = cnt[b];
+  u32* dst = part + ((size_t)w * nch + g) * G::NCOARSE;
+  for (int b = threadIdx.x; b < G::NCOARSE; b += 1024) dst[b] = cnt[b];
 }
 // A2. totals over the chunks, exclusive scan over all ncb = NWIN * NCOARSE coarse bins (one workgroup), cursors per chunk
-static __global__ void __launch_bounds__(256) coarse_totals_kernel(const u32* part, int ncb, int nch, u32* tot) {
+static __global__ void __launch_bounds__(256) coarse_totals_kernel(const u32* part, int ncb, int ncoarse, int nch, u32* tot) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ncb) return;
-  const int w = j / NCOARSE, cb = j % NCOARSE;
+  const int w = j / ncoarse, cb = j % ncoarse;
   u32 s = 0;
 #pragma unroll 1
-  for (int g = 0; g < nch; g++) s += part[((size_t)w * nch + g) * NCOARSE + cb];
+  for (int g = 0; g < nch; g++) s += part[((size_t)w * nch + g) * ncoarse + cb];
   tot[j] = s;
 }
 static __global__ void __launch_bounds__(1024) coarse_scan_kernel(const u32* tot, int ncb, u32* coarse_off, u32* total_entries) {
@@ -182,34 +220,36 @@ static __global__ void __launch_bounds__(1024) coarse_scan_kernel(const u32* tot
   for (int q = 0; q < per; q++) { const int j = t * per + q; if (j < ncb) { coarse_off[j] = run; run += tot[j]; } }
   if (t == 1023) { coarse_off[ncb] = psum[1023]; *total_entries = psum[1023]; }    // one past the end: the number of sorted entries
 }
-static __global__ void __launch_bounds__(256) coarse_cursors_kernel(u32* part, int ncb, int nch, const u32* coarse_off) {
+static __global__ void __launch_bounds__(256) coarse_cursors_kernel(u32* part, int ncb, int ncoarse, int nch, const u32* coarse_off) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ncb) return;
-  const int w = j / NCOARSE, cb = j % NCOARSE;
+  const int w = j / ncoarse, cb = j % ncoarse;
   u32 run = coarse_off[j];
 #pragma unroll 1
   for (int g = 0; g < nch; g++) {
-    u32* p = part + ((size_t)w * nch + g) * NCOARSE + cb;
+    u32* p = part + ((size_t)w * nch + g) * ncoarse + cb;
     const u32 c = *p;
     *p = run;
     run += c;
   }
 }
-// A3. entries into their coarse bins; same workgroup -> (window, chunk) map as the histogram.  The carry window (the last
-//     one) holds a single bucket, so its entries are final after this level and go straight to `sorted`.
-static __global__ void __launch_bounds__(1024) coarse_scatter_kernel(const uint16_t* mag, const u32* sgn, size_t n, size_t ns, int nhalf, int nwin, int nch,
+// A3. entries into their coarse bins; same workgroup -> (window, chunk) map as the histogram.  A carry window (`carry_win`,
+//     -1 if there is none) holds a single bucket, so its entries are final after this level and go straight to `sorted`.
+template <int CB>
+__global__ void __launch_bounds__(1024) coarse_scatter_kernel(const typename Geo<CB>::Mag* mag, const u32* sgn, size_t n, size_t ns, int nhalf, int carry_win, int nch,
                                                               const u32* part, u32* mid, u32* sorted) {
-  __shared__ u32 cur[NCOARSE];
+  using G = Geo<CB>;
+  __shared__ u32 cur[G::NCOARSE];
   const int w = blockIdx.x / nch, g = blockIdx.x % nch;
-  const u32* src = part + ((size_t)w * nch + g) * NCOARSE;
-  for (int b = threadIdx.x; b < NCOARSE; b += 1024) cur[b] = src[b];
+  const u32* src = part + ((size_t)w * nch + g) * G::NCOARSE;
+  for (int b = threadIdx.x; b < G::NCOARSE; b += 1024) cur[b] = src[b];
   __syncthreads();
   size_t lo, hi;
   chunk_range(n, g, nch, lo, hi);
-  u32* dst = (w == nwin - 1) ? sorted : mid;
+  u32* dst = (w == carry_win) ? sorted : mid;
 #pragma unroll 1
   for (int h = 0; h < nhalf; h++) {
-    const uint16_t* m = mag + (size_t)(nhalf * w + h) * ns;
+    const typename G::Mag* m = mag + (size_t)(nhalf * w + h) * ns;
     for (size_t i = lo + 4 * (size_t)threadIdx.x; i < hi; i += 4096) {       // four terms per step: the loads go out together
       u32 a[4];
       load_mag4(a, m, i);
@@ -219,20 +259,23 @@ static __global__ void __launch_bounds__(1024) coarse_scatter_kernel(const uint1
       for (int q = 0; q < 4; q++) {
         if (a[q] && i + q < hi) {
           const u32 b = a[q] - 1;
-          const u32 pos = atomicAdd(&cur[b >> LOG_FINE], 1u);
-          dst[pos] = (u32)(i + q) | ((b & (NFINE - 1)) << 24) | ((u32)h << 30) | (((sg[q] >> (nhalf * w + h)) & 1u) << 31);
+          const u32 pos = atomicAdd(&cur[b >> G::LOG_FINE], 1u);
+          dst[pos] = (u32)(i + q) | ((b & (G::NFINE - 1)) << G::INDEX_BITS) | ((u32)h << 30) | (((sg[q] >> (nhalf * w + h)) & 1u) << 31);
         }
       }
     }
   }
 }
-// B. one workgroup per coarse bin: count its entries per bucket, scan the 64 counts (which are the bucket offsets of the
+// B. one workgroup per coarse bin: count its entries per bucket, scan the NFINE counts (which are the bucket offsets of the
 //    whole sort: offsets[(w * NCOARSE + cb) * NFINE + f] is bucket w * NBUCKET + cb * NFINE + f), place the entries.
-static __global__ void __launch_bounds__(256) fine_sort_kernel(const u32* mid, const u32* coarse_off, int nwin, u32* offsets, u32* sorted) {
-  __shared__ u32 cnt[NFINE], cur[NFINE];
+template <int CB>
+__global__ void __launch_bounds__(256) fine_sort_kernel(const u32* mid, const u32* coarse_off, int carry_win, u32* offsets, u32* sorted) {
+  using G = Geo<CB>;
+  constexpr int NFINE = G::NFINE;
+  __shared__ u32 cnt[NFINE], cur[NFINE], scn[NFINE];
   const int j = blockIdx.x, t = threadIdx.x;
   const u32 lo = coarse_off[j], hi = coarse_off[j + 1];
-  if (j >= (nwin - 1) * NCOARSE) {             // carry window: every entry of the bin is in its first bucket, already in place
+  if (carry_win >= 0 && j >= carry_win * G::NCOARSE) {     // carry window: every entry of the bin is in its first bucket, already in place
     if (t < NFINE) offsets[(size_t)j * NFINE + t] = (t == 0) ? lo : hi;
     return;
   }
@@ -240,57 +283,73 @@ static __global__ void __launch_bounds__(256) fine_sort_kernel(const u32* mid, c
   __syncthreads();
   // entries lo .. hi: a scalar head up to the next multiple of four, then 16-byte loads
   const u32 lo4 = (lo + 3u) & ~3u, head = (lo4 < hi ? lo4 : hi);
-  if (lo + t < head) atomicAdd(&cnt[(mid[lo + t] >> 24) & (NFINE - 1)], 1u);
+  if (lo + t < head) atomicAdd(&cnt[(mid[lo + t] >> G::INDEX_BITS) & (NFINE - 1)], 1u);
   for (u32 e = head + 4 * t; e < hi; e += 1024) {
     const uint4 v4 = *(const uint4*)(mid + e);                  // mid is padded by four entries
     const u32 v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
     for (int q = 0; q < 4; q++)
-      if (e + q < hi) atomicAdd(&cnt[(v[q] >> 24) & (NFINE - 1)], 1u);
+      if (e + q < hi) atomicAdd(&cnt[(v[q] >> G::INDEX_BITS) & (NFINE - 1)], 1u);
   }
   __syncthreads();
-  if (t < NFINE) {                             // exclusive scan of 64 counts in the first wave
-    const u32 c = cnt[t];
-    u32 incl = c;
-#pragma unroll
-    for (int off = 1; off < NFINE; off <<= 1) {
-      const u32 v = __shfl_up(incl, off);
-      if (t >= off) incl += v;
-    }
-    const u32 start = lo + incl - c;
+  // exclusive scan of the NFINE counts
+  if (t < NFINE) scn[t] = cnt[t];
+  __syncthreads();
+#pragma unroll 1
+  for (int off = 1; off < NFINE; off <<= 1) {
+    const u32 v = (t < NFINE && t >= off) ? scn[t - off] : 0u;
+    __syncthreads();
+    if (t < NFINE) scn[t] += v;
+    __syncthreads();
+  }
+  if (t < NFINE) {
+    const u32 start = lo + scn[t] - cnt[t];
     cur[t] = start;
     offsets[(size_t)j * NFINE + t] = start;
   }
   __syncthreads();
   if (lo + t < head) {
     const u32 v = mid[lo + t];
-    sorted[atomicAdd(&cur[(v >> 24) & (NFINE - 1)], 1u)] = v;
+    sorted[atomicAdd(&cur[(v >> G::INDEX_BITS) & (NFINE - 1)], 1u)] = v;
   }
   for (u32 e = head + 4 * t; e < hi; e += 1024) {
     const uint4 v4 = *(const uint4*)(mid + e);
     const u32 v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
     for (int q = 0; q < 4; q++)
-      if (e + q < hi) sorted[atomicAdd(&cur[(v[q] >> 24) & (NFINE - 1)], 1u)] = v[q];
+      if (e + q < hi) sorted[atomicAdd(&cur[(v[q] >> G::INDEX_BITS) & (NFINE - 1)], 1u)] = v[q];
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 4. bucket sums.  A bucket with more than `cap` entries would serialise the launch on a few lanes (equal scalars - a
-//    plain sum of points is an MSM with all scalars 1 - put every term of a window into one bucket), so such buckets are
-//    only registered here: they are cut into chunks of `cap` entries, each chunk is summed by a whole workgroup
-//    (heavy_chunk_kernel) and the chunk sums are folded per bucket (heavy_finish_kernel).  With uniform scalars only the
-//    carry windows' single buckets are heavy.
+// 3. Bucket sums over equal runs of the sorted entries.
+//    The sorted array is cut into `ntask` runs of `len` consecutive entries (len = task_len(total, ntask)); lane t sums
+//    run t in an XYZZ accumulator.  When the run leaves a bucket the accumulator is stored and cleared:
+//      - a bucket that begins and ends inside the run is complete: it goes to bucketsX[b];
+//      - a bucket that began before the run is the run's HEAD piece (head[t]); it may also extend past the run's end;
+//      - a bucket that begins inside the run (or exactly at its start) and extends past its end is the TAIL piece
+//        (tail[t]), and the lane appends the bucket to the list of buckets in pieces.
+//    A bucket b in pieces that covers runs t0 < t1 is tail[t0] + head[t0 + 1] + .. + head[t1] (span_combine_kernel; a
+//    bucket over more than SPAN_MAX runs - equal scalars put every term of a window into one bucket - is summed by
+//    whole workgroups).  Every lane performs the same number of additions whatever the bucket sizes: no lane of a wave
+//    waits for a longer bucket (one lane per bucket part, the previous version, lost 6 % at 512 entries per bucket and
+//    would lose 30 % at 64), and over-full buckets need no separate accumulation path.
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr u32 MSM_MIN_RUN = 16;                   // shortest run (small sums: fewer, longer runs than lanes)
+constexpr u32 SPAN_MAX = 64, HEAVY_CHUNK = 4096;  // pieces one lane folds; pieces per workgroup of the heavy path
+__host__ __device__ __forceinline__ u32 task_len(u32 total, u32 ntask) {
+  const u32 len = (u32)(((u64)total + ntask - 1) / ntask);
+  return len < MSM_MIN_RUN ? MSM_MIN_RUN : len;
+}
 struct HeavyBucket { u32 bucket, base, chunks; };
 struct HeavyChunk { u32 bucket, index; };
 
 // the prepared point an entry names: 2 NW words in the field's internal form (16-byte loads)
 template <class C>
 struct RawPoint { uint4 v[C::NW / 2]; };
-template <class C>
+template <class C, int CB>
 __device__ __forceinline__ RawPoint<C> entry_point(const u32* prep, size_t n, u32 e) {
-  const uint4* src = (const uint4*)(prep + ((size_t)((e >> 30) & 1u) * n + (e & ENTRY_INDEX_MASK)) * 2 * C::NW);
+  const uint4* src = (const uint4*)(prep + ((size_t)((e >> 30) & 1u) * n + (e & Geo<CB>::INDEX_MASK)) * 2 * C::NW);
   RawPoint<C> r;
 #pragma unroll
   for (int q = 0; q < C::NW / 2; q++) r.v[q] = src[q];
@@ -315,72 +374,119 @@ __device__ __forceinline__ void bucket_add_raw(Xyzz<C>& acc, const RawPoint<C>& 
   if (e >> 31) C::fe_neg(y, y);
   xyzz_add_mixed<C>(acc, x, y);
 }
-// acc += the points of entries s .. e, software-pipelined: the gather of entry q + 1 is in flight during the addition of entry q
 template <class C>
-__device__ __forceinline__ void bucket_accumulate_run(Xyzz<C>& acc, const u32* prep, size_t n, const u32* sorted, u32 s, u32 e) {
-  if (s >= e) return;
-  u32 en = sorted[s];
-  RawPoint<C> pn = entry_point<C>(prep, n, en);
-#pragma unroll 1
-  for (u32 q = s; q < e; q++) {
-    const u32 ec = en;
-    const RawPoint<C> pc = pn;
-    if (q + 1 < e) {
-      en = sorted[q + 1];
-      pn = entry_point<C>(prep, n, en);
-    }
-    bucket_add_raw<C>(acc, pc, ec);
-  }
+__device__ __forceinline__ void store_xyzz(Xyzz<C>* dst, const Xyzz<C>& p) {
+  constexpr int NW = C::NW;
+  uint4* d = (uint4*)dst;
+  const typename C::Fe* f[4] = {&p.x, &p.y, &p.zz, &p.zzz};
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int q = 0; q < NW / 4; q++) d[k * (NW / 4) + q] = make_uint4(f[k]->v[4 * q], f[k]->v[4 * q + 1], f[k]->v[4 * q + 2], f[k]->v[4 * q + 3]);
 }
-// One lane per (bucket, part): a bucket's run of entries is cut into `split` equal parts summed by `split` neighbouring
-// lanes, and bucket_combine_kernel adds the parts.  With one lane per bucket the 294 912 buckets of a 2^23-term k256 sum
-// were 1.125 x the 262 144 lanes the chip holds at this kernel's occupancy - a second, almost empty round as long as the
-// first; eight parts per bucket make it nine full rounds of shorter tasks, handed out by the dispatcher as CUs free up.
 template <class C>
-__global__ void __launch_bounds__(256, 4) bucket_sum_kernel(const u32* prep, size_t n, const u32* offsets, const u32* sorted, Jac<C>* parts, int nb, int split,
-                                                            u32 cap, u32* heavy_ctr, HeavyBucket* heavy, HeavyChunk* chunks) {
-  ECGPU_GRID_STRIDE(t, (size_t)nb * split) {
-    const size_t b = t / split;
-    const u32 j = (u32)(t % split);
+__device__ __forceinline__ void load_xyzz_as_jacobian(Jac<C>& r, const Xyzz<C>* src) {
+  const Xyzz<C> p = *src;
+  xyzz_to_jacobian<C>(r, p);
+}
+
+template <class C, int CB>
+__global__ void __launch_bounds__(256, 4) bucket_sum_kernel(const u32* prep, size_t n, const u32* offsets, const u32* sorted, int nb, u32 ntask, Xyzz<C>* bucketsX,
+                                                            Xyzz<C>* head, Xyzz<C>* tail, u32* span_ctr, u32* span_list) {
+  const u32 total = offsets[nb];
+  const u32 len = task_len(total, ntask);
+  ECGPU_GRID_STRIDE(tt, (size_t)ntask) {
+    const u32 t = (u32)tt;
+    const u64 s64 = (u64)t * len;
+    if (s64 >= total) break;                      // runs are handed out in order: every later one of this lane is empty too
+    const u32 s = (u32)s64, e = (total - s < len) ? total : s + len;
+    // the bucket of entry s: offsets[b] <= s < offsets[b + 1]
+    u32 lo = 0, hi = (u32)nb;
+    while (hi - lo > 1) {
+      const u32 mid = (lo + hi) >> 1;
+      if (offsets[mid] <= s) lo = mid; else hi = mid;
+    }
+    u32 b = lo, bend = offsets[b + 1];
+    bool is_head = offsets[b] < s;                // the first bucket began in an earlier run
     Xyzz<C> acc;
     xyzz_set_infinity<C>(acc);
-    const u32 lo = offsets[b], hi = offsets[b + 1], len = hi - lo;
-    if (len > cap) {
-      if (j == 0) {
-        const u32 k = (len + cap - 1) / cap;
-        const u32 idx = atomicAdd(&heavy_ctr[0], 1u);
-        const u32 base = atomicAdd(&heavy_ctr[1], k);
-        heavy[idx] = HeavyBucket{(u32)b, base, k};
+    u32 en = sorted[s];
+    RawPoint<C> pn = entry_point<C, CB>(prep, n, en);
 #pragma unroll 1
-        for (u32 q = 0; q < k; q++) chunks[base + q] = HeavyChunk{(u32)b, q};
+    for (u32 q = s; q < e; q++) {
+      if (q == bend) {                            // bucket b ended at q: it is complete unless it is the head piece
+        store_xyzz<C>(is_head ? &head[t] : &bucketsX[b], acc);
+        xyzz_set_infinity<C>(acc);
+        is_head = false;
+        do { b++; bend = offsets[b + 1]; } while (bend <= q);      // skip empty buckets
       }
-      continue;                                   // parts of a heavy bucket are not read: heavy_finish_kernel writes its sum
+      const u32 ec = en;
+      const RawPoint<C> pc = pn;
+      if (q + 1 < e) {                            // software pipeline: the gather of entry q + 1 is in flight during the addition of entry q
+        en = sorted[q + 1];
+        pn = entry_point<C, CB>(prep, n, en);
+      }
+      bucket_add_raw<C>(acc, pc, ec);
     }
-    const u32 s = lo + (u32)(((u64)len * j) / split), e = lo + (u32)(((u64)len * (j + 1)) / split);
-    bucket_accumulate_run<C>(acc, prep, n, sorted, s, e);
-    Jac<C> r;
-    xyzz_to_jacobian<C>(r, acc);
-    parts[t] = r;
+    // the last bucket of the run
+    if (is_head) {
+      store_xyzz<C>(&head[t], acc);
+    } else if (bend > e) {
+      store_xyzz<C>(&tail[t], acc);
+      span_list[atomicAdd(span_ctr, 1u)] = b;
+    } else {
+      store_xyzz<C>(&bucketsX[b], acc);
+    }
   }
 }
-// buckets[b] = sum of its parts (general additions; a heavy bucket's sum is written by heavy_finish_kernel)
+// piece p of a bucket that starts in run t0: p = 0 is tail[t0], p >= 1 is head[t0 + p]
 template <class C>
-__global__ void __launch_bounds__(256) bucket_combine_kernel(const Jac<C>* parts, Jac<C>* buckets, int nb, int split, const u32* offsets, u32 cap) {
-  ECGPU_GRID_STRIDE(b, (size_t)nb) {
-    if (offsets[b + 1] - offsets[b] > cap) continue;
-    Jac<C> acc = parts[b * split];
+__device__ __forceinline__ void load_piece(Jac<C>& r, const Xyzz<C>* head, const Xyzz<C>* tail, u32 t0, u32 p) {
+  load_xyzz_as_jacobian<C>(r, p == 0 ? &tail[t0] : &head[t0 + p]);
+}
+// buckets in pieces: fold the pieces (few) or register the bucket for the workgroup path (many)
+template <class C, int CB>
+__global__ void __launch_bounds__(256) span_combine_kernel(const u32* offsets, int nb, u32 ntask, const u32* span_ctr, const u32* span_list, const Xyzz<C>* head,
+                                                           const Xyzz<C>* tail, Xyzz<C>* bucketsX, u32* heavy_ctr, HeavyBucket* heavy, HeavyChunk* chunks) {
+  const u32 len = task_len(offsets[nb], ntask);
+  const u32 count = *span_ctr;
+  ECGPU_GRID_STRIDE(i, (size_t)count) {
+    const u32 b = span_list[i];
+    const u32 t0 = offsets[b] / len, t1 = (offsets[b + 1] - 1) / len, np = t1 - t0 + 1;
+    if (np > SPAN_MAX) {
+      const u32 k = (np + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
+      const u32 idx = atomicAdd(&heavy_ctr[0], 1u);
+      const u32 base = atomicAdd(&heavy_ctr[1], k);
+      heavy[idx] = HeavyBucket{b, base, k};
 #pragma unroll 1
-    for (int j = 1; j < split; j++) pt_add<C>(acc, acc, parts[b * split + j]);
-    buckets[b] = acc;
+      for (u32 q = 0; q < k; q++) chunks[base + q] = HeavyChunk{b, q};
+      continue;
+    }
+    Jac<C> acc, pc;
+    load_piece<C>(acc, head, tail, t0, 0);
+#pragma unroll 1
+    for (u32 p = 1; p < np; p++) {
+      load_piece<C>(pc, head, tail, t0, p);
+      pt_add<C>(acc, acc, pc);
+    }
+    Xyzz<C> r;
+    jacobian_to_xyzz<C>(r, acc);
+    store_xyzz<C>(&bucketsX[b], r);
   }
 }
 
-// sum over the lanes of a workgroup through LDS (count = blockDim.x, a power of two)
+// sum over the lanes of a workgroup through LDS (sh holds 256 points; count = 256 or 512 lanes)
 template <class C>
 __device__ __forceinline__ void lds_tree_sum(Jac<C>* sh, Jac<C>& v, int lane, int count) {
-  sh[lane] = v;
+  if (count == 512) {                             // fold the upper half first
+    if (lane >= 256) sh[lane - 256] = v;
+    __syncthreads();
+    if (lane < 256) { Jac<C> b = sh[lane]; pt_add<C>(v, v, b); }
+    __syncthreads();
+  }
+  if (lane < 256) sh[lane] = v;
   __syncthreads();
-  for (int off = count >> 1; off >= 1; off >>= 1) {
+  for (int off = 128; off >= 1; off >>= 1) {
     if (lane < off) {
       Jac<C> a = sh[lane], b = sh[lane + off];
       pt_add<C>(a, a, b);
@@ -391,30 +497,31 @@ __device__ __forceinline__ void lds_tree_sum(Jac<C>* sh, Jac<C>& v, int lane, in
   v = sh[0];
   __syncthreads();
 }
-// 4b. one workgroup per chunk of a heavy bucket: lanes stride over the chunk, LDS tree sum
-template <class C>
-__global__ void __launch_bounds__(256) heavy_chunk_kernel(const u32* prep, size_t n, const u32* offsets, const u32* sorted, u32 cap, const u32* heavy_ctr,
-                                                          const HeavyChunk* chunks, Jac<C>* partial) {
+// one workgroup per chunk of HEAVY_CHUNK pieces of a heavy bucket: lanes stride over the pieces, LDS tree sum
+template <class C, int CB>
+__global__ void __launch_bounds__(256) heavy_chunk_kernel(const u32* offsets, int nb, u32 ntask, const u32* heavy_ctr, const HeavyChunk* chunks, const Xyzz<C>* head,
+                                                          const Xyzz<C>* tail, Jac<C>* partial) {
   __shared__ Jac<C> sh[256];
+  const u32 len = task_len(offsets[nb], ntask);
   const u32 total = heavy_ctr[1];
   for (u32 c = blockIdx.x; c < total; c += gridDim.x) {
     const HeavyChunk ch = chunks[c];
-    const u32 lo = offsets[ch.bucket] + ch.index * cap;
-    const u32 end = offsets[ch.bucket + 1];
-    const u32 hi = (end - lo > cap) ? lo + cap : end;
-    Xyzz<C> xacc;
-    xyzz_set_infinity<C>(xacc);
+    const u32 t0 = offsets[ch.bucket] / len, t1 = (offsets[ch.bucket + 1] - 1) / len, np = t1 - t0 + 1;
+    const u32 plo = ch.index * HEAVY_CHUNK, phi = (np - plo > HEAVY_CHUNK) ? plo + HEAVY_CHUNK : np;
+    Jac<C> acc, pc;
+    jac::set_infinity<C>(acc);
 #pragma unroll 1
-    for (u32 j = lo + threadIdx.x; j < hi; j += 256) { const u32 e = sorted[j]; bucket_add_raw<C>(xacc, entry_point<C>(prep, n, e), e); }
-    Jac<C> acc;
-    xyzz_to_jacobian<C>(acc, xacc);
+    for (u32 p = plo + threadIdx.x; p < phi; p += 256) {
+      load_piece<C>(pc, head, tail, t0, p);
+      pt_add<C>(acc, acc, pc);
+    }
     lds_tree_sum<C>(sh, acc, threadIdx.x, 256);
     if (threadIdx.x == 0) partial[c] = acc;
   }
 }
-// 4c. one workgroup per heavy bucket: fold its chunk sums
+// one workgroup per heavy bucket: fold its chunk sums
 template <class C>
-__global__ void __launch_bounds__(256) heavy_finish_kernel(const u32* heavy_ctr, const HeavyBucket* heavy, const Jac<C>* partial, Jac<C>* buckets) {
+__global__ void __launch_bounds__(256) heavy_finish_kernel(const u32* heavy_ctr, const HeavyBucket* heavy, const Jac<C>* partial, Xyzz<C>* bucketsX) {
   __shared__ Jac<C> sh[256];
   const u32 total = heavy_ctr[0];
   for (u32 h = blockIdx.x; h < total; h += gridDim.x) {
@@ -424,80 +531,89 @@ __global__ void __launch_bounds__(256) heavy_finish_kernel(const u32* heavy_ctr,
 #pragma unroll 1
     for (u32 j = threadIdx.x; j < hb.chunks; j += 256) pt_add<C>(acc, acc, partial[hb.base + j]);
     lds_tree_sum<C>(sh, acc, threadIdx.x, 256);
-    if (threadIdx.x == 0) buckets[hb.bucket] = acc;
+    if (threadIdx.x == 0) {
+      Xyzz<C> r;
+      jacobian_to_xyzz<C>(r, acc);
+      store_xyzz<C>(&bucketsX[hb.bucket], r);
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 5. Weighted sums by a tree of running sums.  For a run of L points B_0..B_{L-1},
-//      T = sum B_t   and   Wt = sum (t + 1) B_t
-//    come from 2L additions (run += B_t from the top, wt += run).  Level 0 does this for every SEG0
-//    consecutive buckets; level 1 for every SEG1 consecutive level-0 results; the window kernel
-//    finishes.  With weights nested as j + 1 = (s1 * SEG1 + s0) * SEG0 + t + 1:
-//      S = sum_j (j+1) B_j = sum Wt0 + SEG0 * [ sum_{s1} ( (Wt1 - T1) ) + SEG1 * sum_{s1} s1 * T1 ]
-//    where T1/Wt1 are the level-1 sums over the level-0 totals T0 (Wt1 weights them 1..SEG1).
+// 4. Weighted sums sum_j (j + 1) B_j of a window's buckets by a tree of running sums.  A node that covers `size`
+//    consecutive buckets carries
+//      T = sum B_j   and   W = sum (j' + 1) B_j   (j' = position of the bucket inside the node),
+//    and a parent of children 0 .. M-1 (each of `size` buckets) has
+//      T' = sum_i T_i,   W' = sum_i W_i + size * sum_i i T_i.
+//    sum_i i T_i comes from running sums from the top (run += T_i, acc += run for i = M-1 .. 1).  The level that reads the
+//    buckets has W_i = T_i = B_i and size = 1, i.e. run / acc over i = M-1 .. 0.  Levels shrink by M = 8 until NTOP = 512
+//    nodes per window are left; one workgroup per window finishes (lane i: i T_i by double-and-add, LDS tree sums).
 // ---------------------------------------------------------------------------------------------------------------------
-template <class C>
-__global__ void __launch_bounds__(64) segment_kernel(const Jac<C>* in, Jac<C>* out_t, Jac<C>* out_w, int len, int total) {
+template <class C, int CB>
+__global__ void __launch_bounds__(64) level0_kernel(const Xyzz<C>* bucketsX, const u32* offsets, Jac<C>* out_t, Jac<C>* out_w, int total) {
+  constexpr int M = Geo<CB>::M;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= total) return;
-  const Jac<C>* B = in + (size_t)s * len;
-  Jac<C> run, wt;
+  Jac<C> run, wt, bj;
   jac::set_infinity<C>(run);
   wt = run;
 #pragma unroll 1
-  for (int t = len - 1; t >= 0; t--) {
-    pt_add<C>(run, run, B[t]);
+  for (int t = M - 1; t >= 0; t--) {
+    const size_t b = (size_t)s * M + t;
+    if (offsets[b + 1] != offsets[b]) {            // an empty bucket was never written
+      load_xyzz_as_jacobian<C>(bj, &bucketsX[b]);
+      pt_add<C>(run, run, bj);
+    }
     pt_add<C>(wt, wt, run);
   }
   out_t[s] = run;
   out_w[s] = wt;
 }
-// plain sums of `len` consecutive points (for the sum of the level-0 weighted parts)
-template <class C>
-__global__ void __launch_bounds__(64) sum_kernel(const Jac<C>* in, Jac<C>* out, int len, int total) {
+template <class C, int CB>
+__global__ void __launch_bounds__(64) level_kernel(const Jac<C>* in_t, const Jac<C>* in_w, Jac<C>* out_t, Jac<C>* out_w, int log_size, int total) {
+  constexpr int M = Geo<CB>::M;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= total) return;
-  Jac<C> acc;
-  jac::set_infinity<C>(acc);
+  const Jac<C>* T = in_t + (size_t)s * M;
+  const Jac<C>* W = in_w + (size_t)s * M;
+  Jac<C> run, acc, ws;
+  jac::set_infinity<C>(run);
+  acc = run;
+  ws = W[0];
 #pragma unroll 1
-  for (int t = 0; t < len; t++) pt_add<C>(acc, acc, in[(size_t)s * len + t]);
-  out[s] = acc;
-}
-
-// 6. per window: combine NSEG1 level-1 results
-//      S_w = sumW0 + SEG0 * ( sum_{s1} (Wt1 - T1)  +  SEG1 * sum_{s1} s1 * T1 )
-//    One workgroup per window, lane s1 owns one level-1 segment (and one of the NSUMW partial sums of the level-0
-//    weighted parts); the three sums over the lanes are LDS tree reductions, so the dependent chain is
-//    log2(NSEG1) additions instead of NSEG1 x 4.
-template <class C>
-__global__ void __launch_bounds__(NSEG1) window_kernel(const Jac<C>* t1, const Jac<C>* w1, const Jac<C>* sumw0, Jac<C>* win) {
-  static_assert(NSUMW == NSEG1 && NSEG1 <= 1024, "one lane per level-1 segment and per partial sum");
-  __shared__ Jac<C> sh[NSEG1];
-  const int w = blockIdx.x, s = threadIdx.x;          // blockDim.x == NSEG1
-  Jac<C> inner, acc, sw;
-  jac::set_infinity<C>(acc);
-  const Jac<C> T = t1[w * NSEG1 + s];
-  Jac<C> neg = T;
-  C::fe_neg(neg.y, neg.y);
-  pt_add<C>(inner, w1[w * NSEG1 + s], neg);            // Wt1 - T1
-  // s * T by double-and-add over the bits of s
-#pragma unroll 1
-  for (int bit = LOG_NSEG1 - 1; bit >= 0; bit--) {
-    pt_dbl<C>(acc);
-    if ((s >> bit) & 1) pt_add<C>(acc, acc, T);
+  for (int i = M - 1; i >= 1; i--) {
+    pt_add<C>(run, run, T[i]);
+    pt_add<C>(acc, acc, run);
+    pt_add<C>(ws, ws, W[i]);
   }
-  sw = sumw0[w * NSUMW + s];
-  lds_tree_sum<C>(sh, inner, s, NSEG1);
-  lds_tree_sum<C>(sh, acc, s, NSEG1);
-  lds_tree_sum<C>(sh, sw, s, NSEG1);
-  if (s == 0) {
+  pt_add<C>(run, run, T[0]);
 #pragma unroll 1
-    for (int j = 0; j < LOG_SEG1; j++) pt_dbl<C>(acc);
-    pt_add<C>(acc, acc, inner);
+  for (int j = 0; j < log_size; j++) pt_dbl<C>(acc);
+  pt_add<C>(ws, ws, acc);
+  out_t[s] = run;
+  out_w[s] = ws;
+}
+// per window: S_w = sum_i W_i + size * sum_i i T_i over the NTOP nodes that are left
+template <class C, int CB>
+__global__ void __launch_bounds__(Geo<CB>::NTOP) window_kernel(const Jac<C>* in_t, const Jac<C>* in_w, int log_size, Jac<C>* win) {
+  using G = Geo<CB>;
+  __shared__ Jac<C> sh[256];
+  const int w = blockIdx.x, i = threadIdx.x;          // blockDim.x == NTOP
+  const Jac<C> T = in_t[(size_t)w * G::NTOP + i];
+  Jac<C> acc, ws = in_w[(size_t)w * G::NTOP + i];
+  jac::set_infinity<C>(acc);
+  // i * T by double-and-add over the bits of i
 #pragma unroll 1
-    for (int j = 0; j < LOG_SEG0; j++) pt_dbl<C>(acc);
-    pt_add<C>(acc, acc, sw);
+  for (int bit = G::LOG_NTOP - 1; bit >= 0; bit--) {
+    pt_dbl<C>(acc);
+    if ((i >> bit) & 1) pt_add<C>(acc, acc, T);
+  }
+  lds_tree_sum<C>(sh, acc, i, G::NTOP);
+  lds_tree_sum<C>(sh, ws, i, G::NTOP);
+  if (i == 0) {
+#pragma unroll 1
+    for (int j = 0; j < log_size; j++) pt_dbl<C>(acc);
+    pt_add<C>(acc, acc, ws);
     win[w] = acc;
   }
 }
@@ -549,9 +665,9 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const Jac<C>* partial
   if (threadIdx.x == 0) win[0] = acc;                  // finish_kernel with nwin = 1 converts and stores it
 }
 
-// 7. Horner over the windows, conversion to affine, output
+// 5. Horner over the windows (`cbits` doublings per window), conversion to affine, output
 template <class C>
-__global__ void __launch_bounds__(64) finish_kernel(const Jac<C>* win, int nwin, u32* out, int out_fmt) {
+__global__ void __launch_bounds__(64) finish_kernel(const Jac<C>* win, int nwin, int cbits, u32* out, int out_fmt) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   constexpr int NW = C::NW;
   using Fe = typename C::Fe;
@@ -559,7 +675,7 @@ __global__ void __launch_bounds__(64) finish_kernel(const Jac<C>* win, int nwin,
 #pragma unroll 1
   for (int w = nwin - 2; w >= 0; w--) {
 #pragma unroll 1
-    for (int j = 0; j < CBITS; j++) pt_dbl<C>(r);
+    for (int j = 0; j < cbits; j++) pt_dbl<C>(r);
     pt_add<C>(r, r, win[w]);
   }
   const bool inf = C::fe_is_zero(r.z);
@@ -585,87 +701,67 @@ __global__ void __launch_bounds__(256) to_affine_kernel(const u32* xyz, u32* xy,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Host side: all stages on c->stream out of one grow-only workspace.  `mul` is the curve's batch scalar multiplication
-// (used for small sums).
+// Host side: all stages on c->stream out of one grow-only workspace.
 // ---------------------------------------------------------------------------------------------------------------------
-#ifndef MSM_BUCKET_WGS_PER_CU
-#define MSM_BUCKET_WGS_PER_CU 64     // cap on bucket-sum workgroups per CU: above tasks / 256, so every lane takes one task and the dispatcher balances the CUs
+#ifndef MSM_ROUNDS
+#define MSM_ROUNDS 4                 // bucket-sum runs per resident lane (ECGPU_MSM_ROUNDS)
 #endif
-#ifndef MSM_BUCKET_SPLIT
-#define MSM_BUCKET_SPLIT 8           // lanes per bucket (bucket_sum_kernel)
-#endif
-template <class C, class MulFn>
-static int msm_run(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt, MulFn mul) {
-  constexpr int NW = C::NW, NHALF = Cfg<C>::NHALF, NWIN = Cfg<C>::NWIN, NDIG = Cfg<C>::NDIG;
-  constexpr int NCB = NWIN * NCOARSE;
-  using J = Jac<C>;
-  static_assert((size_t)NDIG * SLAB_TERMS < ((size_t)1 << 32) && SLAB_TERMS - 1 <= ENTRY_INDEX_MASK, "32-bit offsets and 24-bit term indices within a slab");
-  if (((uintptr_t)pts & 15) || ((uintptr_t)sc & 3)) return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_msm: device points must be 16-byte aligned");
-  const size_t nb = (size_t)NWIN * NBUCKET;
-  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  auto reserve = [&](size_t need) -> int {
-    if (need > c->msm_ws_cap) {
-      if (c->msm_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->msm_ws)); c->msm_ws = nullptr; c->msm_ws_cap = 0; }
-      HIPCHK(c, hipMalloc(&c->msm_ws, need));
-      c->msm_ws_cap = need;
-    }
-    return 0;
-  };
-  // ECGPU_MSM_SMALL = 0 forces the bucket method for every size (measurements, tests of the bucket path on small inputs)
-  // (read per call so that one process can exercise both paths)
-  const char* small_env = getenv("ECGPU_MSM_SMALL");
-  const bool small_path = !(small_env && atoi(small_env) == 0);
-  if (small_path && n > 0 && n < SMALL_MSM_TERMS) {
-    // n scalar multiplications on the throughput kernel, then a two-level sum of the products
-    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    const size_t sz_prod = al(n * 8 * NW), sz_part = al((size_t)blocks * sizeof(J)), sz_win = al(sizeof(J));
-    int rc = reserve(sz_prod + sz_part + sz_win);
-    if (rc) return rc;
-    char* p = (char*)c->msm_ws;
-    u32* prod = (u32*)p; p += sz_prod;
-    J* partial = (J*)p; p += sz_part;
-    J* win = (J*)p;
-    if ((rc = mul(sc, pts, pt_fmt, prod, n))) return rc;
-    hipLaunchKernelGGL((sum_affine_kernel<C>), dim3(blocks), dim3(256), 0, c->stream, (const u32*)prod, n, partial);
-    hipLaunchKernelGGL((sum_partials_kernel<C>), dim3(1), dim3(256), 0, c->stream, (const J*)partial, blocks, win);
-    hipLaunchKernelGGL((finish_kernel<C>), dim3(1), dim3(64), 0, c->stream, (const J*)win, 1, out, out_fmt);
-    HIPCHK(c, hipGetLastError());
-    return 0;
+static inline size_t msm_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static int msm_reserve(ecgpu_ctx* c, size_t need) {
+  if (need > c->msm_ws_cap) {
+    if (c->msm_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->msm_ws)); c->msm_ws = nullptr; c->msm_ws_cap = 0; }
+    HIPCHK(c, hipMalloc(&c->msm_ws, need));
+    c->msm_ws_cap = need;
   }
-  // Large sums run in slabs of at most SLAB_TERMS terms (a sorted entry keeps the term index in 24 bits); every slab goes
-  // through the whole pipeline down to its NWIN window sums, which are added up before the final Horner pass.
+  return 0;
+}
+
+// the bucket method with CB-bit windows
+template <class C, int CB>
+static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt) {
+  using G = Geo<CB>;
+  using K = Cfg<C, CB>;
+  using J = Jac<C>;
+  using X = Xyzz<C>;
+  using Mag = typename G::Mag;
+  constexpr int NW = C::NW, NHALF = K::NHALF, NWIN = K::NWIN, NDIG = K::NDIG;
+  constexpr int NCB = NWIN * G::NCOARSE;
+  constexpr int CARRY_WIN = K::HAS_CARRY ? NWIN - 1 : -1;
+  static_assert((size_t)NDIG * G::SLAB_TERMS < ((size_t)1 << 32), "32-bit offsets within a slab");
+  auto al = msm_align;
+  const size_t nb = (size_t)NWIN * G::NBUCKET;
+  // Large sums run in slabs of at most SLAB_TERMS terms (a sorted entry keeps the term index in INDEX_BITS bits); every
+  // slab goes through the whole pipeline down to its NWIN window sums, which are added up before the final Horner pass.
   // ECGPU_MSM_SLAB overrides the slab size (tests exercise the slab loop on small inputs).
   const char* slab_env = getenv("ECGPU_MSM_SLAB");
-  size_t slab = slab_env ? (size_t)atoll(slab_env) : SLAB_TERMS;
-  if (slab < 1024 || slab > SLAB_TERMS) slab = SLAB_TERMS;
+  size_t slab = slab_env ? (size_t)atoll(slab_env) : G::SLAB_TERMS;
+  if (slab < 1024 || slab > G::SLAB_TERMS) slab = G::SLAB_TERMS;
   const size_t m = n < slab ? n : slab;                // terms of the largest slab: sizes the workspace
+  // bucket-sum runs: `rounds` per lane the chip holds at that kernel's occupancy (4 workgroups of 256 per CU)
+  static const int rounds = [] { const char* e = getenv("ECGPU_MSM_ROUNDS"); int v = e ? atoi(e) : MSM_ROUNDS; return (v < 1 || v > 64) ? MSM_ROUNDS : v; }();
+  const u32 ntask = (u32)rounds * (u32)c->num_cus * 1024u;
   const size_t sz_aff = (pt_fmt == FMT_PROJECTIVE) ? al(m * 8 * NW) : 0, sz_prep = al((size_t)NHALF * m * 8 * NW);
   const size_t sz_off = al((nb + 1) * 4), sz_coff = al((size_t)(NCB + 1) * 4), sz_tot = al((size_t)NCB * 4), sz_sorted = al((size_t)NDIG * m * 4 + 32);
   // level A of the sort: one 1024-thread workgroup per CU, the chunks of a window side by side
-  // (ECGPU_MSM_CHUNK_WGS workgroups per CU, default 1: measurements)
-  static const int chunk_wgs = [] { const char* e = getenv("ECGPU_MSM_CHUNK_WGS"); int v = e ? atoi(e) : 1; return (v < 1 || v > 8) ? 1 : v; }();
-  const int nch = (chunk_wgs * c->num_cus - 1) / NWIN > 0 ? (chunk_wgs * c->num_cus - 1) / NWIN : 1;
-  const size_t sz_part = al((size_t)NWIN * nch * NCOARSE * 4);
+  const int nch = (c->num_cus - 1) / NWIN > 0 ? (c->num_cus - 1) / NWIN : 1;
+  const size_t sz_part = al((size_t)NWIN * nch * G::NCOARSE * 4);
   const size_t ms = (m + 3) & ~(size_t)3;              // row stride of the digit arrays: four terms per load
-  const size_t sz_mag = al((size_t)NDIG * ms * 2), sz_sgn = al(ms * 4);
-  static const int wgs_per_cu = [] { const char* e = getenv("ECGPU_MSM_WGS"); int v = e ? atoi(e) : MSM_BUCKET_WGS_PER_CU; return (v < 1 || v > 1024) ? MSM_BUCKET_WGS_PER_CU : v; }();
-  static const int split = [] { const char* e = getenv("ECGPU_MSM_SPLIT"); int v = e ? atoi(e) : MSM_BUCKET_SPLIT; return (v < 1 || v > 64) ? MSM_BUCKET_SPLIT : v; }();
-  const size_t sz_buckets = al(nb * sizeof(J)), sz_parts = al(nb * split * sizeof(J));
-  const size_t n0 = (size_t)NWIN * NSEG0, n1 = (size_t)NWIN * NSEG1, nsw = (size_t)NWIN * NSUMW;
-  const size_t sz_l0 = al(n0 * sizeof(J)), sz_l1 = al(n1 * sizeof(J)), sz_sw = al(nsw * sizeof(J)), sz_win = al(NWIN * sizeof(J));
-  // heavy buckets (more than `cap` entries): at most L / cap of them, at most 2 L / cap + 1 chunks
-  const size_t L = (size_t)NDIG * m;
-  const u32 cap = (u32)((8 * NHALF * (m / NBUCKET) > 2048) ? 8 * NHALF * (m / NBUCKET) : 2048);
-  const size_t hmax = L / cap + 1, cmax = 2 * (L / cap) + 2;
-  const size_t sz_hctr = al(8), sz_heavy = al(hmax * sizeof(HeavyBucket)), sz_chunks = al(cmax * sizeof(HeavyChunk)), sz_partial = al(cmax * sizeof(J));
-  const size_t need = sz_aff + sz_prep + sz_mag + sz_sgn + sz_off + sz_coff + sz_tot + sz_part + 2 * sz_sorted + sz_buckets + sz_parts + 2 * sz_l0 + 2 * sz_l1 +
-                      sz_sw + 2 * sz_win + sz_hctr + sz_heavy + sz_chunks + sz_partial;
-  int rc = reserve(need);
+  const size_t sz_mag = al((size_t)NDIG * ms * sizeof(Mag)), sz_sgn = al(ms * 4);
+  const size_t sz_bx = al(nb * sizeof(X)), sz_piece = al((size_t)ntask * sizeof(X)), sz_span = al((size_t)ntask * 4 + 8);
+  const size_t n0 = nb / G::M;                         // nodes of the level that reads the buckets
+  const size_t sz_l0 = al(n0 * sizeof(J)), sz_l1 = al(n0 / G::M * sizeof(J)), sz_win = al(NWIN * sizeof(J));
+  // a run leaves at most two pieces (head and tail), so there are at most 2 ntask pieces: at most 2 ntask / SPAN_MAX buckets
+  // over more than SPAN_MAX runs, cut into at most 2 ntask / HEAVY_CHUNK + one chunk each
+  const size_t hmax = 2 * (size_t)ntask / SPAN_MAX + 1, cmax = 2 * (size_t)ntask / HEAVY_CHUNK + hmax + 1;
+  const size_t sz_ctr = al(16), sz_heavy = al(hmax * sizeof(HeavyBucket)), sz_chunks = al(cmax * sizeof(HeavyChunk)), sz_partial = al(cmax * sizeof(J));
+  const size_t need = sz_aff + sz_prep + sz_mag + sz_sgn + sz_off + sz_coff + sz_tot + sz_part + 2 * sz_sorted + sz_bx + 2 * sz_piece + sz_span + 2 * sz_l0 + 2 * sz_l1 +
+                      2 * sz_win + sz_ctr + sz_heavy + sz_chunks + sz_partial;
+  int rc = msm_reserve(c, need);
   if (rc) return rc;
   char* p = (char*)c->msm_ws;
   u32* aff = (u32*)p; p += sz_aff;
   u32* prep = (u32*)p; p += sz_prep;
-  uint16_t* mag = (uint16_t*)p; p += sz_mag;
+  Mag* mag = (Mag*)p; p += sz_mag;
   u32* sgn = (u32*)p; p += sz_sgn;
   u32* offsets = (u32*)p; p += sz_off;
   u32* coarse_off = (u32*)p; p += sz_coff;
@@ -673,16 +769,17 @@ static int msm_run(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size
   u32* part = (u32*)p; p += sz_part;
   u32* mid = (u32*)p; p += sz_sorted;
   u32* sorted = (u32*)p; p += sz_sorted;
-  J* buckets = (J*)p; p += sz_buckets;
-  J* parts = (J*)p; p += sz_parts;
-  J* t0 = (J*)p; p += sz_l0;
-  J* w0 = (J*)p; p += sz_l0;
-  J* t1 = (J*)p; p += sz_l1;
-  J* w1 = (J*)p; p += sz_l1;
-  J* sumw0 = (J*)p; p += sz_sw;
+  X* bucketsX = (X*)p; p += sz_bx;
+  X* head = (X*)p; p += sz_piece;
+  X* tail = (X*)p; p += sz_piece;
+  u32* span_list = (u32*)p; p += sz_span;
+  J* ta = (J*)p; p += sz_l0;
+  J* wa = (J*)p; p += sz_l0;
+  J* tb = (J*)p; p += sz_l1;
+  J* wb = (J*)p; p += sz_l1;
   J* win = (J*)p; p += sz_win;
   J* win_slab = (J*)p; p += sz_win;
-  u32* heavy_ctr = (u32*)p; p += sz_hctr;
+  u32* ctr = (u32*)p; p += sz_ctr;                     // [0] buckets in pieces, [2] heavy buckets, [3] heavy chunks
   HeavyBucket* heavy = (HeavyBucket*)p; p += sz_heavy;
   HeavyChunk* chunks = (HeavyChunk*)p; p += sz_chunks;
   J* partial = (J*)p;
@@ -697,32 +794,77 @@ static int msm_run(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size
       xy = aff;
     }
     J* wdst = (s0 == 0) ? win : win_slab;
-    hipLaunchKernelGGL((digits_kernel<C>), dim3(ecgpu_grid_for(c, cnt, 8)), dim3(256), 0, c->stream, ssc, cnt, ms, mag, sgn);
+    hipLaunchKernelGGL((digits_kernel<C, CB>), dim3(ecgpu_grid_for(c, cnt, 8)), dim3(256), 0, c->stream, ssc, cnt, ms, mag, sgn);
     hipLaunchKernelGGL((prepare_points_kernel<C>), dim3(ecgpu_grid_for(c, cnt, 8)), dim3(256), 0, c->stream, xy, prep, cnt);
-    hipLaunchKernelGGL(coarse_hist_kernel, dim3((unsigned)(NWIN * nch)), dim3(1024), 0, c->stream, (const uint16_t*)mag, cnt, ms, NHALF, nch, part);
-    hipLaunchKernelGGL(coarse_totals_kernel, dim3(cb_grid), dim3(256), 0, c->stream, (const u32*)part, NCB, nch, tot);
+    hipLaunchKernelGGL((coarse_hist_kernel<CB>), dim3((unsigned)(NWIN * nch)), dim3(1024), 0, c->stream, (const Mag*)mag, cnt, ms, NHALF, nch, part);
+    hipLaunchKernelGGL(coarse_totals_kernel, dim3(cb_grid), dim3(256), 0, c->stream, (const u32*)part, NCB, G::NCOARSE, nch, tot);
     hipLaunchKernelGGL(coarse_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u32*)tot, NCB, coarse_off, offsets + nb);
-    hipLaunchKernelGGL(coarse_cursors_kernel, dim3(cb_grid), dim3(256), 0, c->stream, part, NCB, nch, (const u32*)coarse_off);
-    hipLaunchKernelGGL(coarse_scatter_kernel, dim3((unsigned)(NWIN * nch)), dim3(1024), 0, c->stream, (const uint16_t*)mag, (const u32*)sgn, cnt, ms, NHALF, NWIN, nch,
+    hipLaunchKernelGGL(coarse_cursors_kernel, dim3(cb_grid), dim3(256), 0, c->stream, part, NCB, G::NCOARSE, nch, (const u32*)coarse_off);
+    hipLaunchKernelGGL((coarse_scatter_kernel<CB>), dim3((unsigned)(NWIN * nch)), dim3(1024), 0, c->stream, (const Mag*)mag, (const u32*)sgn, cnt, ms, NHALF, CARRY_WIN, nch,
                        (const u32*)part, mid, sorted);
-    hipLaunchKernelGGL(fine_sort_kernel, dim3((unsigned)NCB), dim3(256), 0, c->stream, (const u32*)mid, (const u32*)coarse_off, NWIN, offsets, sorted);
-    HIPCHK(c, hipMemsetAsync(heavy_ctr, 0, 8, c->stream));
-    hipLaunchKernelGGL((bucket_sum_kernel<C>), dim3(ecgpu_grid_for(c, nb * split, wgs_per_cu)), dim3(256), 0, c->stream, (const u32*)prep, cnt, (const u32*)offsets,
-                       (const u32*)sorted, parts, (int)nb, split, cap, heavy_ctr, heavy, chunks);
-    hipLaunchKernelGGL((heavy_chunk_kernel<C>), dim3((unsigned)c->num_cus * 8), dim3(256), 0, c->stream, (const u32*)prep, cnt, (const u32*)offsets, (const u32*)sorted, cap,
-                       (const u32*)heavy_ctr, (const HeavyChunk*)chunks, partial);
-    hipLaunchKernelGGL((heavy_finish_kernel<C>), dim3((unsigned)c->num_cus), dim3(256), 0, c->stream, (const u32*)heavy_ctr, (const HeavyBucket*)heavy, (const J*)partial,
-                       buckets);
-    hipLaunchKernelGGL((bucket_combine_kernel<C>), dim3(ecgpu_grid_for(c, nb, 8)), dim3(256), 0, c->stream, (const J*)parts, buckets, (int)nb, split, (const u32*)offsets, cap);
-    hipLaunchKernelGGL((segment_kernel<C>), dim3((unsigned)((n0 + 63) / 64)), dim3(64), 0, c->stream, (const J*)buckets, t0, w0, SEG0, (int)n0);
-    hipLaunchKernelGGL((segment_kernel<C>), dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, c->stream, (const J*)t0, t1, w1, SEG1, (int)n1);
-    hipLaunchKernelGGL((sum_kernel<C>), dim3((unsigned)((nsw + 63) / 64)), dim3(64), 0, c->stream, (const J*)w0, sumw0, SUMW_LEN, (int)nsw);
-    hipLaunchKernelGGL((window_kernel<C>), dim3(NWIN), dim3(NSEG1), 0, c->stream, (const J*)t1, (const J*)w1, (const J*)sumw0, wdst);
+    hipLaunchKernelGGL((fine_sort_kernel<CB>), dim3((unsigned)NCB), dim3(256), 0, c->stream, (const u32*)mid, (const u32*)coarse_off, CARRY_WIN, offsets, sorted);
+    HIPCHK(c, hipMemsetAsync(ctr, 0, 16, c->stream));
+    hipLaunchKernelGGL((bucket_sum_kernel<C, CB>), dim3(ntask / 256), dim3(256), 0, c->stream, (const u32*)prep, cnt, (const u32*)offsets, (const u32*)sorted, (int)nb, ntask,
+                       bucketsX, head, tail, ctr, span_list);
+    hipLaunchKernelGGL((span_combine_kernel<C, CB>), dim3(ecgpu_grid_for(c, ntask, 8)), dim3(256), 0, c->stream, (const u32*)offsets, (int)nb, ntask, (const u32*)ctr,
+                       (const u32*)span_list, (const X*)head, (const X*)tail, bucketsX, ctr + 2, heavy, chunks);
+    hipLaunchKernelGGL((heavy_chunk_kernel<C, CB>), dim3((unsigned)c->num_cus * 4), dim3(256), 0, c->stream, (const u32*)offsets, (int)nb, ntask, (const u32*)(ctr + 2),
+                       (const HeavyChunk*)chunks, (const X*)head, (const X*)tail, partial);
+    hipLaunchKernelGGL((heavy_finish_kernel<C>), dim3((unsigned)c->num_cus), dim3(256), 0, c->stream, (const u32*)(ctr + 2), (const HeavyBucket*)heavy, (const J*)partial,
+                       bucketsX);
+    // the tree: buckets -> nb / 8 nodes -> .. -> NTOP nodes per window -> window sums
+    size_t nodes = n0;
+    hipLaunchKernelGGL((level0_kernel<C, CB>), dim3((unsigned)((nodes + 63) / 64)), dim3(64), 0, c->stream, (const X*)bucketsX, (const u32*)offsets, ta, wa, (int)nodes);
+    J *it = ta, *iw = wa, *ot = tb, *ow = wb;
+    int log_size = G::LOG_M;
+    for (int lv = 1; lv < G::NLEVEL; lv++) {
+      nodes /= G::M;
+      hipLaunchKernelGGL((level_kernel<C, CB>), dim3((unsigned)((nodes + 63) / 64)), dim3(64), 0, c->stream, (const J*)it, (const J*)iw, ot, ow, log_size, (int)nodes);
+      J* t = it; it = ot; ot = t;
+      t = iw; iw = ow; ow = t;
+      log_size += G::LOG_M;
+    }
+    hipLaunchKernelGGL((window_kernel<C, CB>), dim3(NWIN), dim3(G::NTOP), 0, c->stream, (const J*)it, (const J*)iw, log_size, wdst);
     if (s0 != 0) hipLaunchKernelGGL((windows_accumulate_kernel<C>), dim3(1), dim3(64), 0, c->stream, win, (const J*)win_slab, NWIN);
   }
-  hipLaunchKernelGGL((finish_kernel<C>), dim3(1), dim3(64), 0, c->stream, (const J*)win, (int)NWIN, out, out_fmt);
+  hipLaunchKernelGGL((finish_kernel<C>), dim3(1), dim3(64), 0, c->stream, (const J*)win, (int)NWIN, CB, out, out_fmt);
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+
+// `mul` is the curve's batch scalar multiplication (used for small sums).
+// ECGPU_MSM_SMALL = 0 forces the bucket method for every size, ECGPU_MSM_CBITS = 16 | 19 one window width (both read per
+// call so that one process can exercise every path: measurements, tests of the bucket paths on small inputs).
+constexpr size_t WIDE_WINDOW_TERMS = (size_t)1 << 21;     // sums from this size on use 19-bit windows
+template <class C, class MulFn>
+static int msm_run(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt, MulFn mul) {
+  constexpr int NW = C::NW;
+  using J = Jac<C>;
+  if (((uintptr_t)pts & 15) || ((uintptr_t)sc & 3)) return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_msm: device points must be 16-byte aligned");
+  const char* small_env = getenv("ECGPU_MSM_SMALL");
+  const bool small_path = !(small_env && atoi(small_env) == 0);
+  if (small_path && n > 0 && n < SMALL_MSM_TERMS) {
+    // n scalar multiplications on the throughput kernel, then a two-level sum of the products
+    auto al = msm_align;
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    const size_t sz_prod = al(n * 8 * NW), sz_part = al((size_t)blocks * sizeof(J)), sz_win = al(sizeof(J));
+    int rc = msm_reserve(c, sz_prod + sz_part + sz_win);
+    if (rc) return rc;
+    char* p = (char*)c->msm_ws;
+    u32* prod = (u32*)p; p += sz_prod;
+    J* partial = (J*)p; p += sz_part;
+    J* win = (J*)p;
+    if ((rc = mul(sc, pts, pt_fmt, prod, n))) return rc;
+    hipLaunchKernelGGL((sum_affine_kernel<C>), dim3(blocks), dim3(256), 0, c->stream, (const u32*)prod, n, partial);
+    hipLaunchKernelGGL((sum_partials_kernel<C>), dim3(1), dim3(256), 0, c->stream, (const J*)partial, blocks, win);
+    hipLaunchKernelGGL((finish_kernel<C>), dim3(1), dim3(64), 0, c->stream, (const J*)win, 1, 0, out, out_fmt);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  const char* cb_env = getenv("ECGPU_MSM_CBITS");
+  const int cb = cb_env ? atoi(cb_env) : 0;
+  const bool wide = (cb == 19) || (cb != 16 && n >= WIDE_WINDOW_TERMS);
+  return wide ? msm_buckets<C, 19>(c, sc, pts, pt_fmt, n, out, out_fmt) : msm_buckets<C, 16>(c, sc, pts, pt_fmt, n, out, out_fmt);
 }
 
 }  // namespace msm

@@ -13,20 +13,27 @@ C = M.K256
 N = C.n
 
 
-@pytest.fixture(scope="module", params=["auto", "buckets"])
-def curve(request):
-    """Every test runs twice: with the library's own choice (below 2^19 terms: n scalar multiplications and a tree
-    sum) and with the bucket method forced for all sizes (ECGPU_MSM_SMALL=0, read per call)."""
+def _set_path(path):
+    """"auto": the library's own choice (below 3 * 2^16 terms: n scalar multiplications and a tree sum; 16-bit windows
+    below 2^21 terms, 19-bit windows from there on); "buckets16" / "buckets19": the bucket method with that window width
+    forced for all sizes (ECGPU_MSM_SMALL=0, ECGPU_MSM_CBITS: both read per call)."""
     import os
-    import ecgpu
-    if request.param == "buckets":
+    os.environ.pop("ECGPU_MSM_SMALL", None)
+    os.environ.pop("ECGPU_MSM_CBITS", None)
+    if path != "auto":
         os.environ["ECGPU_MSM_SMALL"] = "0"
-    else:
-        os.environ.pop("ECGPU_MSM_SMALL", None)
+        os.environ["ECGPU_MSM_CBITS"] = path[-2:]
+
+
+@pytest.fixture(scope="module", params=["auto", "buckets16", "buckets19"])
+def curve(request):
+    """Every test runs three times: see _set_path."""
+    import ecgpu
+    _set_path(request.param)
     ctx = ecgpu.Context(0)
     yield ctx.curve("k256")
     ctx.close()
-    os.environ.pop("ECGPU_MSM_SMALL", None)
+    _set_path("auto")
 
 
 def arr(rows, w):
@@ -116,8 +123,9 @@ def test_structured_large(curve):
 
 
 def test_heavy_buckets_equal_scalars(curve):
-    """Equal scalars put every term of a window into one bucket: those buckets are cut into chunks summed by whole
-    workgroups (msm_kernels.hpp step 4).  n = 20000 > cap = 2048, against the oracle's term-by-term sum."""
+    """Equal scalars put every term of a window into one bucket: such a bucket is left in pieces by more than SPAN_MAX
+    runs of the bucket sums and folded by whole workgroups (msm_kernels.hpp step 3).  n = 20000, against the oracle's
+    term-by-term sum."""
     cv = curve
     n = 20000
     pts = CO.synth_points(0, n, synth.SEED, 4242)
@@ -141,8 +149,6 @@ def test_slabs_of_a_large_sum():
     ECGPU_MSM_SLAB shrinks the slab so that the loop - three slabs, the last one ragged - runs on 2^16 + 777 terms."""
     import os
     import ecgpu
-    os.environ["ECGPU_MSM_SMALL"] = "0"
-    os.environ["ECGPU_MSM_SLAB"] = "30000"
     try:
         ctx = ecgpu.Context(0)
         cv = ctx.curve("k256")
@@ -152,10 +158,13 @@ def test_slabs_of_a_large_sum():
         p[40000] = 0
         s[50000] = 0
         want = CO.msm_naive(0, s, p)
-        assert bytes(cv.msm(s, p)) == bytes(want[:64]) and want[64] == 0
+        for path in ("buckets16", "buckets19"):
+            _set_path(path)
+            os.environ["ECGPU_MSM_SLAB"] = "30000"
+            assert bytes(cv.msm(s, p)) == bytes(want[:64]) and want[64] == 0, path
         ctx.close()
     finally:
-        os.environ.pop("ECGPU_MSM_SMALL", None)
+        _set_path("auto")
         os.environ.pop("ECGPU_MSM_SLAB", None)
 
 
@@ -173,18 +182,17 @@ def _oracle_sum(cid, c, s, p, threads=16):
 
 
 @pytest.mark.parametrize("cn,cid", [("p256", 1), ("p384", 2)])
-@pytest.mark.parametrize("path", ["auto", "buckets"])
+@pytest.mark.parametrize("path", ["auto", "buckets16", "buckets19"])
 def test_nist_msm(cn, cid, path):
-    """The bucket method on the curves without an endomorphism (one half-term per term, 16 / 24 windows, sign fold
-    k > n/2 -> n - k): edge cases against the big-integer model, 2^13 unstructured terms against the C oracle, and
+    """The bucket method on the curves without an endomorphism (one half-term per term, 16 / 24 windows of 16 bits and a
+    carry window, or 14 / 21 windows of 19 bits; sign fold k > n/2 -> n - k): edge cases against the big-integer model, 2^13 unstructured terms against the C oracle, and
     2^18 structured terms P_i = (a0 + i d) G against the closed form (sum k_i (a0 + i d) mod n) G."""
     import os
     import torch
     import ecgpu
     c = M.CURVES[cn]
     nb, n_ord = c.nbytes, c.n
-    if path == "buckets":
-        os.environ["ECGPU_MSM_SMALL"] = "0"
+    _set_path(path)
     try:
         ctx = ecgpu.Context(0)
         cv = ctx.curve(cn)
@@ -210,7 +218,7 @@ def test_nist_msm(cn, cid, path):
         assert bytes(cv.msm(s, p)) == M.i2b(c, want[0]) + M.i2b(c, want[1])
         got = cv.msm(s, p, out_format=ecgpu.PROJECTIVE)
         assert bytes(got) == M.i2b(c, want[0]) + M.i2b(c, want[1]) + M.i2b(c, 1)
-        if path == "buckets":
+        if path != "auto":
             # structured: 2^18 terms through the full-size pipeline
             n = 1 << 18
             a0, d = 0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321
@@ -230,7 +238,7 @@ def test_nist_msm(cn, cid, path):
             assert bytes(d_out.cpu().numpy()) == M.i2b(c, w[0]) + M.i2b(c, w[1])
         ctx.close()
     finally:
-        os.environ.pop("ECGPU_MSM_SMALL", None)
+        _set_path("auto")
 
 
 @pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1)])
@@ -254,16 +262,17 @@ def test_bucket_path_agrees_with_term_by_term_path_on_awkward_sizes(cn, cid):
     try:
         for n in (1, 2, 3, 5, 63, 64, 65, 255, 257, 1023, 1025, 4093, 4095, 4097, 32767, 65537, 131071, 131075):
             s, p = s_all[:n], p_all[:n]
-            os.environ.pop("ECGPU_MSM_SMALL", None)
+            _set_path("auto")
             os.environ.pop("ECGPU_MSM_SLAB", None)
             a = bytes(cv.msm(s, p))
-            os.environ["ECGPU_MSM_SMALL"] = "0"
-            b = bytes(cv.msm(s, p))
-            assert a == b, n
-            if n > 5000:
-                os.environ["ECGPU_MSM_SLAB"] = "4099"      # ragged slabs (not a multiple of four)
-                assert bytes(cv.msm(s, p)) == a, ("slabs", n)
+            for path in ("buckets16", "buckets19"):
+                _set_path(path)
+                os.environ.pop("ECGPU_MSM_SLAB", None)
+                assert bytes(cv.msm(s, p)) == a, (path, n)
+                if n > 5000:
+                    os.environ["ECGPU_MSM_SLAB"] = "4099"      # ragged slabs (not a multiple of four)
+                    assert bytes(cv.msm(s, p)) == a, (path, "slabs", n)
     finally:
-        os.environ.pop("ECGPU_MSM_SMALL", None)
+        _set_path("auto")
         os.environ.pop("ECGPU_MSM_SLAB", None)
         ctx.close()
