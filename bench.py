@@ -68,9 +68,10 @@ WORK = {
     # 96 windows x 4 doublings (4M+4S) + 89 mixed additions (97 digits x 15/16, first one a copy) + table (4 dbl,
     # 3 general additions 11M+5S) + table to affine 8 x (6M+1S) + (385S+14M)/8 + output normalise 6M+1S + (385S+14M)/8
     "p384_varbase": (1536 + 89 * 8 + 49 + 48 + 14 / 8 + 6 + 14 / 8, 1536 + 89 * 3 + 31 + 8 + 385 / 8 + 1 + 385 / 8),
-    # bucket method with GLV halves: 2 x 8 windows -> 16 XYZZ mixed additions (8M+2S) per term + ~0.6 carry-window entries;
-    # per-term share of the endomorphism (1M), bucket parts -> Jacobian and their combination, reduction tree (~3 % together)
-    "k256_msm": (16.6 * 8 + 1 + 4, 16.6 * 2 + 1),
+    # bucket method with GLV halves, 7 windows of 18 / 19 bits at this size: 14 XYZZ mixed additions (8M+2S) per term;
+    # per-term share of the endomorphism (1M), of the bucket pieces and of the bucket reduction (1.8 M buckets: XYZZ -> Jacobian
+    # and two general additions 12M+4S each; 1.5 M pieces folded) ~ 9M + 3S
+    "k256_msm": (14 * 8 + 1 + 9, 14 * 2 + 3),
     # verification = u2 Q (headline kernel) + u1 G (20-bit table) + prep / check (57 scalar-field equivalents + 7)
     "k256_ecdsa_verify": (87 + 128 * 3 + 66 * 15 / 16 * 8 + 9 + 12 * 8 + 6 + 64, 29 + 128 * 4 + 66 * 15 / 16 * 3 + 9 + 12 * 3 + 5),
     # p256 verification = u2 Q (vb::mul_kernel<CurveP256,8,4>: 256 doublings 4M+4S, 60 general additions 11M+5S, table 4 dbl + 3 add,

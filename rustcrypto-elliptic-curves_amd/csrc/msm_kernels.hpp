@@ -11,7 +11,7 @@ namespace msm {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Geometry of one window width CB (bits of a signed digit): buckets, the two levels of the sort, the sorted entry, the
-// reduction tree.  Two widths are instantiated: 16 (sums below 2^21 terms) and 19.
+// reduction tree.  Two widths are instantiated: 16 and 19 (see msm_run for which sizes take which).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int CB>
 struct Geo {
@@ -23,10 +23,11 @@ struct Geo {
   static constexpr int INDEX_BITS = 30 - LOG_FINE;
   static constexpr u32 INDEX_MASK = (1u << INDEX_BITS) - 1u;
   static constexpr size_t SLAB_TERMS = (size_t)1 << INDEX_BITS;      // a call is cut into slabs of this many terms
-  // reduction tree: M children per node and level, down to NTOP nodes per window (one workgroup finishes a window)
-  static constexpr int LOG_M = 3, M = 1 << LOG_M, LOG_NTOP = 9, NTOP = 1 << LOG_NTOP;
-  static constexpr int NLEVEL = (CB - 1 - LOG_NTOP) / LOG_M;         // levels including the one that reads the buckets
-  static_assert((CB - 1 - LOG_NTOP) % LOG_M == 0 && NLEVEL >= 1, "the tree must end at NTOP nodes");
+  // reduction: a lane of the first level takes M buckets; 256 of its nodes make a group, NG groups a window
+  static constexpr int LOG_M = 3, M = 1 << LOG_M;
+  static constexpr int LOG_NG = 4, NG = 1 << LOG_NG;                 // 16 groups = 4096 nodes per window enter the group kernel
+  static constexpr int NMID = (CB - 1 - LOG_M - 8 - LOG_NG) / LOG_M; // M-ary levels between the bucket level and the groups (0 or 1)
+  static_assert((CB - 1 - LOG_M - 8 - LOG_NG) % LOG_M == 0 && NMID >= 0, "the levels must end at 4096 nodes per window");
   using Mag = typename std::conditional<(CB <= 16), uint16_t, u32>::type;   // storage of a digit magnitude (0 .. 2^(CB-1))
 };
 // per-curve shape of the digit matrix
@@ -36,12 +37,20 @@ struct Cfg {
   static constexpr int BITS = C::A_IS_ZERO ? 128 : 32 * C::NW;       // bits of a (half-)scalar magnitude
   static constexpr int NREAL = (BITS + CB - 1) / CB;                 // windows that cover them
   // a window width that divides BITS leaves no room for the carry of the signed recoding: one more window with a single
-  // bucket takes it.  Otherwise the top window holds fewer than CB - 1 bits and its digit stays positive.
+  // bucket takes it (CB = 16).  Otherwise the windows have room to spare, and the spare bits are taken from the LOW windows,
+  // one each (NARROW windows of CB - 1 bits): leaving them all to the top window (14 of 19 bits for secp256k1) would put
+  // that window's entries into 1/32 of its buckets and coarse bins - the sort's workgroup-per-bin level then waits for 128
+  // bins of sixteen times the size.  With CB - 1 bits a window fills half its buckets, which the sort does not notice.
   static constexpr bool HAS_CARRY = (NREAL * CB == BITS);
+  static constexpr int CAP = BITS + (C::A_IS_ZERO ? 1 : 0);          // bits the windows must hold: |k1|, |k2| < 2^128 plus the carry; k <= n/2 < 2^(BITS-1) plus the carry
+  static constexpr int SPARE = HAS_CARRY ? 0 : NREAL * CB - CAP;
+  static constexpr int NARROW = SPARE < NREAL ? SPARE : NREAL;
   static constexpr int NWIN = NREAL + (HAS_CARRY ? 1 : 0);
   static constexpr int NDIG = NWIN * NHALF;                          // digit columns per term
   static_assert(NDIG <= 32, "one sign bit per digit column");
-  static_assert(HAS_CARRY || BITS - (NREAL - 1) * CB <= CB - 1, "the top digit must fit the bucket range without a carry");
+  static_assert(HAS_CARRY || SPARE >= 0, "the windows must hold the magnitude and the recoding carry");
+  __host__ __device__ static constexpr int width(int w) { return CB - (w < NARROW ? 1 : 0); }       // bits of window w
+  __host__ __device__ static constexpr int pos(int w) { return w * CB - (w < NARROW ? w : NARROW); }  // its lowest bit
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -55,12 +64,12 @@ struct Cfg {
 //    sgn[i] bit NHALF w + h = the entry is subtracted (sign of the digit xor sign of the half).  Terms whose point is the
 //    identity are not filtered here: the bucket sums skip them.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NWORDS, int CB>
-__device__ __forceinline__ u32 window_bits(const u32* k, int w) {
-  const int bit = w * CB, lo = bit >> 5, sh = bit & 31;
+template <int NWORDS>
+__device__ __forceinline__ u32 window_bits(const u32* k, int bit, int width) {
+  const int lo = bit >> 5, sh = bit & 31;
   u32 v = (lo < NWORDS) ? (k[lo] >> sh) : 0u;
-  if (sh + CB > 32 && lo + 1 < NWORDS) v |= k[lo + 1] << (32 - sh);
-  return v & ((1u << CB) - 1u);
+  if (sh + width > 32 && lo + 1 < NWORDS) v |= k[lo + 1] << (32 - sh);
+  return v & ((1u << width) - 1u);
 }
 template <class C, int CB, int NWORDS>
 __device__ __forceinline__ void recode_half(const u32* m, u32 neg, int h, size_t i, size_t ns, typename Geo<CB>::Mag* mag, u32& bits) {
@@ -70,10 +79,11 @@ __device__ __forceinline__ void recode_half(const u32* m, u32 neg, int h, size_t
   u32 carry = 0;
 #pragma unroll
   for (int w = 0; w < K::NREAL; w++) {
-    const u32 v = window_bits<NWORDS, CB>(m, w) + carry;
-    if (w < K::NREAL - 1 || K::HAS_CARRY) carry = (v >= (1u << (CB - 1))) ? 1u : 0u;      // v in [2^(CB-1), 2^CB] becomes v - 2^CB with a carry
-    else carry = 0;                                                                        // top window with spare bits: v <= 2^(CB-1)
-    const int d = (int)v - (int)(carry << CB);
+    const int wd = K::width(w);
+    const u32 v = window_bits<NWORDS>(m, K::pos(w), wd) + carry;
+    if (w < K::NREAL - 1 || K::HAS_CARRY) carry = (v >= (1u << (wd - 1))) ? 1u : 0u;       // v in [2^(wd-1), 2^wd] becomes v - 2^wd with a carry
+    else carry = 0;                                                                        // top window: room for the last carry, v <= 2^(wd-1)
+    const int d = (int)v - (int)(carry << wd);
     mag[(size_t)(NHALF * w + h) * ns + i] = (Mag)(d < 0 ? -d : d);
     bits |= (((d < 0) ? 1u : 0u) ^ neg) << (NHALF * w + h);
   }
@@ -233,16 +243,87 @@ static __global__ void __launch_bounds__(256) coarse_cursors_kernel(u32* part, i
     run += c;
   }
 }
+// Tile scatter, the write side of both sort levels.  A scattered 4-byte store is its own L2 transaction, and 10^8 of them
+// per level were what the sort spent its time on (1.2 TB/s of useful traffic).  A workgroup therefore groups a TILE of
+// entries by key in LDS first - count per key (the LDS atomic also hands out the entry's slot within its key), scan,
+// place - and then copies the tile out in order: lane i stores element i, so the elements of one key go to consecutive
+// addresses from consecutive lanes and a run of r entries costs r / 16 line writes instead of r.
+//   PER entries per thread (registers: e[], the key and the slot packed in ks[], key 0xFFFF = no entry)
+//   lds: buf[TILE] entries, key[TILE], off[NKEY + 1] tile offsets, cnt[NKEY] (zero on entry and on exit), wtot[NT / 64]
+//   cur[NKEY]: where the next entry of each key goes in `dst` (advanced here)
+template <int NKEY, int TILE, int NT>
+struct TileLds {
+  u32 buf[TILE];
+  u32 off[NKEY + 1];
+  u32 cnt[NKEY];
+  u32 cur[NKEY];
+  u32 wtot[NT / 64];
+  uint16_t key[TILE];
+};
+template <int NKEY, int TILE, int NT, int PER>
+__device__ __forceinline__ void tile_scatter(TileLds<NKEY, TILE, NT>& L, const u32* e, u32* ks, u32* dst) {
+  static_assert(PER * NT == TILE && NT % 64 == 0 && NKEY <= 0xFFFF, "tile shape");
+  constexpr int KPT = (NKEY + NT - 1) / NT;                       // counters per thread in the scan
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // 1. count; the returned old value is the entry's slot within its key
+#pragma unroll
+  for (int j = 0; j < PER; j++)
+    if (ks[j] != 0xFFFFu) ks[j] |= atomicAdd(&L.cnt[ks[j]], 1u) << 16;
+  __syncthreads();
+  // 2. exclusive scan of the counters: per thread, per wave (shuffles), across the waves (LDS)
+  u32 v[KPT], local = 0;
+#pragma unroll
+  for (int q = 0; q < KPT; q++) { const int k = tid * KPT + q; v[q] = (k < NKEY) ? L.cnt[k] : 0u; local += v[q]; }
+  u32 incl = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+  if (lane == 63) L.wtot[wave] = incl;
+  __syncthreads();
+  u32 run = incl - local;
+#pragma unroll 1
+  for (int w = 0; w < wave; w++) run += L.wtot[w];
+#pragma unroll
+  for (int q = 0; q < KPT; q++) { const int k = tid * KPT + q; if (k < NKEY) { L.off[k] = run; run += v[q]; } }
+  if (tid == NT - 1) L.off[NKEY] = run;
+  __syncthreads();
+  // 3. place
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const u32 k = ks[j] & 0xFFFFu;
+    if (k != 0xFFFFu) { const u32 pos = L.off[k] + (ks[j] >> 16); L.buf[pos] = e[j]; L.key[pos] = (uint16_t)k; }
+  }
+  __syncthreads();
+  // 4. copy out in tile order
+  const u32 total = L.off[NKEY];
+  for (u32 i = tid; i < total; i += NT) {
+    const u32 k = L.key[i];
+    dst[L.cur[k] + (i - L.off[k])] = L.buf[i];
+  }
+  __syncthreads();
+  // 5. advance the cursors, clear the counters
+#pragma unroll
+  for (int q = 0; q < KPT; q++) { const int k = tid * KPT + q; if (k < NKEY) { L.cur[k] += v[q]; L.cnt[k] = 0; } }
+  __syncthreads();
+}
+
 // A3. entries into their coarse bins; same workgroup -> (window, chunk) map as the histogram.  A carry window (`carry_win`,
 //     -1 if there is none) holds a single bucket, so its entries are final after this level and go straight to `sorted`.
+//     (Slots are 16 bits: a tile holds at most 2^16 entries of one key.)
+template <int CB>
+struct CoarseTile {
+  static constexpr int NT = 1024, PER = 16, TILE = NT * PER;
+  using Lds = TileLds<Geo<CB>::NCOARSE, TILE, NT>;
+};
 template <int CB>
 __global__ void __launch_bounds__(1024) coarse_scatter_kernel(const typename Geo<CB>::Mag* mag, const u32* sgn, size_t n, size_t ns, int nhalf, int carry_win, int nch,
                                                               const u32* part, u32* mid, u32* sorted) {
   using G = Geo<CB>;
-  __shared__ u32 cur[G::NCOARSE];
-  const int w = blockIdx.x / nch, g = blockIdx.x % nch;
+  using T = CoarseTile<CB>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typename T::Lds& L = *reinterpret_cast<typename T::Lds*>(smem);
+  const int w = blockIdx.x / nch, g = blockIdx.x % nch, tid = threadIdx.x;
   const u32* src = part + ((size_t)w * nch + g) * G::NCOARSE;
-  for (int b = threadIdx.x; b < G::NCOARSE; b += 1024) cur[b] = src[b];
+  for (int b = tid; b < G::NCOARSE; b += T::NT) { L.cur[b] = src[b]; L.cnt[b] = 0; }
   __syncthreads();
   size_t lo, hi;
   chunk_range(n, g, nch, lo, hi);
@@ -250,50 +331,66 @@ __global__ void __launch_bounds__(1024) coarse_scatter_kernel(const typename Geo
 #pragma unroll 1
   for (int h = 0; h < nhalf; h++) {
     const typename G::Mag* m = mag + (size_t)(nhalf * w + h) * ns;
-    for (size_t i = lo + 4 * (size_t)threadIdx.x; i < hi; i += 4096) {       // four terms per step: the loads go out together
-      u32 a[4];
-      load_mag4(a, m, i);
-      const uint4 sv = *(const uint4*)(sgn + i);                                  // sgn is padded to ns words as well
-      const u32 sg[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll 1
+    for (size_t t0 = lo; t0 < hi; t0 += T::TILE) {                 // a tile: TILE consecutive terms of this digit column
+      u32 e[T::PER], ks[T::PER];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if (a[q] && i + q < hi) {
+      for (int r = 0; r < T::PER / 4; r++) {
+        const size_t i = t0 + 4 * ((size_t)r * T::NT + tid);
+        u32 a[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
+        if (i < hi) {                                              // rows are padded to ns: reading past n within a row is safe
+          load_mag4(a, m, i);
+          const uint4 sv = *(const uint4*)(sgn + i);
+          sg[0] = sv.x; sg[1] = sv.y; sg[2] = sv.z; sg[3] = sv.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const bool ok = a[q] != 0 && i + q < hi;
           const u32 b = a[q] - 1;
-          const u32 pos = atomicAdd(&cur[b >> G::LOG_FINE], 1u);
-          dst[pos] = (u32)(i + q) | ((b & (G::NFINE - 1)) << G::INDEX_BITS) | ((u32)h << 30) | (((sg[q] >> (nhalf * w + h)) & 1u) << 31);
+          ks[4 * r + q] = ok ? (b >> G::LOG_FINE) : 0xFFFFu;
+          e[4 * r + q] = (u32)(i + q) | ((b & (G::NFINE - 1)) << G::INDEX_BITS) | ((u32)h << 30) | (((sg[q] >> (nhalf * w + h)) & 1u) << 31);
         }
       }
+      tile_scatter<G::NCOARSE, T::TILE, T::NT, T::PER>(L, e, ks, dst);
     }
   }
 }
 // B. one workgroup per coarse bin: count its entries per bucket, scan the NFINE counts (which are the bucket offsets of the
-//    whole sort: offsets[(w * NCOARSE + cb) * NFINE + f] is bucket w * NBUCKET + cb * NFINE + f), place the entries.
+//    whole sort: offsets[(w * NCOARSE + cb) * NFINE + f] is bucket w * NBUCKET + cb * NFINE + f), place the entries tile by tile.
+template <int CB>
+struct FineTile {
+  static constexpr int NT = 256, PER = 16, TILE = NT * PER;
+  using Lds = TileLds<Geo<CB>::NFINE, TILE, NT>;
+};
 template <int CB>
 __global__ void __launch_bounds__(256) fine_sort_kernel(const u32* mid, const u32* coarse_off, int carry_win, u32* offsets, u32* sorted) {
   using G = Geo<CB>;
+  using T = FineTile<CB>;
   constexpr int NFINE = G::NFINE;
-  __shared__ u32 cnt[NFINE], cur[NFINE], scn[NFINE];
-  const int j = blockIdx.x, t = threadIdx.x;
+  __shared__ typename T::Lds L;
+  __shared__ u32 scn[NFINE];
+  // bins are taken from the top window down: its digits have fewer bits (14 of 19 for secp256k1), so its few occupied bins
+  // are the largest and must not be the last to start
+  const int j = (int)(gridDim.x - 1 - blockIdx.x), t = threadIdx.x;
   const u32 lo = coarse_off[j], hi = coarse_off[j + 1];
   if (carry_win >= 0 && j >= carry_win * G::NCOARSE) {     // carry window: every entry of the bin is in its first bucket, already in place
     if (t < NFINE) offsets[(size_t)j * NFINE + t] = (t == 0) ? lo : hi;
     return;
   }
-  if (t < NFINE) cnt[t] = 0;
+  if (t < NFINE) L.cnt[t] = 0;
   __syncthreads();
-  // entries lo .. hi: a scalar head up to the next multiple of four, then 16-byte loads
-  const u32 lo4 = (lo + 3u) & ~3u, head = (lo4 < hi ? lo4 : hi);
-  if (lo + t < head) atomicAdd(&cnt[(mid[lo + t] >> G::INDEX_BITS) & (NFINE - 1)], 1u);
-  for (u32 e = head + 4 * t; e < hi; e += 1024) {
-    const uint4 v4 = *(const uint4*)(mid + e);                  // mid is padded by four entries
-    const u32 v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll 1
+  for (u32 t0 = lo; t0 < hi; t0 += T::TILE) {                // PER loads in flight per thread, then their LDS atomics
+    u32 v[T::PER];
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (e + q < hi) atomicAdd(&cnt[(v[q] >> G::INDEX_BITS) & (NFINE - 1)], 1u);
+    for (int r = 0; r < T::PER; r++) { const u32 i = t0 + (u32)r * T::NT + t; v[r] = (i < hi) ? mid[i] : 0xFFFFFFFFu; }
+#pragma unroll
+    for (int r = 0; r < T::PER; r++)
+      if (t0 + (u32)r * T::NT + t < hi) atomicAdd(&L.cnt[(v[r] >> G::INDEX_BITS) & (NFINE - 1)], 1u);
   }
   __syncthreads();
   // exclusive scan of the NFINE counts
-  if (t < NFINE) scn[t] = cnt[t];
+  if (t < NFINE) scn[t] = L.cnt[t];
   __syncthreads();
 #pragma unroll 1
   for (int off = 1; off < NFINE; off <<= 1) {
@@ -303,21 +400,23 @@ __global__ void __launch_bounds__(256) fine_sort_kernel(const u32* mid, const u3
     __syncthreads();
   }
   if (t < NFINE) {
-    const u32 start = lo + scn[t] - cnt[t];
-    cur[t] = start;
+    const u32 start = lo + scn[t] - L.cnt[t];
+    L.cur[t] = start;
+    L.cnt[t] = 0;
     offsets[(size_t)j * NFINE + t] = start;
   }
   __syncthreads();
-  if (lo + t < head) {
-    const u32 v = mid[lo + t];
-    sorted[atomicAdd(&cur[(v >> G::INDEX_BITS) & (NFINE - 1)], 1u)] = v;
-  }
-  for (u32 e = head + 4 * t; e < hi; e += 1024) {
-    const uint4 v4 = *(const uint4*)(mid + e);
-    const u32 v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll 1
+  for (u32 t0 = lo; t0 < hi; t0 += T::TILE) {
+    u32 e[T::PER], ks[T::PER];
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (e + q < hi) sorted[atomicAdd(&cur[(v[q] >> G::INDEX_BITS) & (NFINE - 1)], 1u)] = v[q];
+    for (int r = 0; r < T::PER; r++) {
+      const u32 i = t0 + (u32)r * T::NT + t;                  // consecutive lanes read consecutive entries
+      const bool ok = i < hi;
+      e[r] = ok ? mid[i] : 0u;
+      ks[r] = ok ? ((e[r] >> G::INDEX_BITS) & (NFINE - 1)) : 0xFFFFu;
+    }
+    tile_scatter<NFINE, T::TILE, T::NT, T::PER>(L, e, ks, sorted);
   }
 }
 
@@ -418,7 +517,17 @@ __global__ void __launch_bounds__(256, 4) bucket_sum_kernel(const u32* prep, siz
         store_xyzz<C>(is_head ? &head[t] : &bucketsX[b], acc);
         xyzz_set_infinity<C>(acc);
         is_head = false;
-        do { b++; bend = offsets[b + 1]; } while (bend <= q);      // skip empty buckets
+        b++;
+        bend = offsets[b + 1];
+        if (bend <= q) {                          // empty buckets ahead (the unused half of a narrow window: 2^17 of them): bisect
+          u32 l = b, h = (u32)nb - 1;             // offsets[l + 1] <= q < offsets[h + 1]
+          while (h - l > 1) {
+            const u32 mid = (l + h) >> 1;
+            if (offsets[mid + 1] <= q) l = mid; else h = mid;
+          }
+          b = h;
+          bend = offsets[b + 1];
+        }
       }
       const u32 ec = en;
       const RawPoint<C> pc = pn;
@@ -540,14 +649,19 @@ __global__ void __launch_bounds__(256) heavy_finish_kernel(const u32* heavy_ctr,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 4. Weighted sums sum_j (j + 1) B_j of a window's buckets by a tree of running sums.  A node that covers `size`
-//    consecutive buckets carries
-//      T = sum B_j   and   W = sum (j' + 1) B_j   (j' = position of the bucket inside the node),
-//    and a parent of children 0 .. M-1 (each of `size` buckets) has
-//      T' = sum_i T_i,   W' = sum_i W_i + size * sum_i i T_i.
-//    sum_i i T_i comes from running sums from the top (run += T_i, acc += run for i = M-1 .. 1).  The level that reads the
-//    buckets has W_i = T_i = B_i and size = 1, i.e. run / acc over i = M-1 .. 0.  Levels shrink by M = 8 until NTOP = 512
-//    nodes per window are left; one workgroup per window finishes (lane i: i T_i by double-and-add, LDS tree sums).
+// 4. Weighted sums S_w = sum_j (j + 1) B_j of a window's buckets, in three kernels with a short dependent chain.
+//    a) level0: a lane takes M = 8 consecutive buckets: T = sum B_j, W = sum (j' + 1) B_j (j' = position inside the node)
+//       by running sums from the top (run += B_j, W += run): 2 M additions.
+//       With the nodes numbered i = 0 .. N-1 in a window:  S_w = sum_i W_i + M * sum_i i T_i.
+//    (19-bit windows: one M-ary level of the same kind in between, W' = sum W_i + size sum i T_i, so that 4096 nodes per
+//    window are left.)
+//    b) group: a workgroup takes 256 consecutive nodes (i = 256 g + l) with three teams of 256 lanes working side by side:
+//         A_g = sum_l W_i,   P_g = sum_l T_i,   Q_g = sum_l l T_i   (l T_i by double-and-add over 8 bits)
+//       each by an LDS tree over its team, so that   sum_i i T_i = 256 sum_g g P_g + sum_g Q_g.
+//    c) window: one workgroup per window, three teams again: sum_g A_g, sum_g g P_g (double-and-add over the bits of g),
+//       sum_g Q_g, then S_w = A + M (256 P + Q) on one lane.
+//    The dependent chain after level0 is about 700 field multiplications (the earlier tree of M-ary running-sum levels
+//    finished by one workgroup had twice that, and it is latency, not throughput, that this stage costs).
 // ---------------------------------------------------------------------------------------------------------------------
 template <class C, int CB>
 __global__ void __launch_bounds__(64) level0_kernel(const Xyzz<C>* bucketsX, const u32* offsets, Jac<C>* out_t, Jac<C>* out_w, int total) {
@@ -569,6 +683,8 @@ __global__ void __launch_bounds__(64) level0_kernel(const Xyzz<C>* bucketsX, con
   out_t[s] = run;
   out_w[s] = wt;
 }
+// an M-ary level: children i = 0 .. M-1 of `size` = 2^log_size buckets each: T' = sum T_i, W' = sum W_i + size sum i T_i
+// (running sums from the top: run += T_i, acc += run for i = M-1 .. 1)
 template <class C, int CB>
 __global__ void __launch_bounds__(64) level_kernel(const Jac<C>* in_t, const Jac<C>* in_w, Jac<C>* out_t, Jac<C>* out_w, int log_size, int total) {
   constexpr int M = Geo<CB>::M;
@@ -593,28 +709,64 @@ __global__ void __launch_bounds__(64) level_kernel(const Jac<C>* in_t, const Jac
   out_t[s] = run;
   out_w[s] = ws;
 }
-// per window: S_w = sum_i W_i + size * sum_i i T_i over the NTOP nodes that are left
-template <class C, int CB>
-__global__ void __launch_bounds__(Geo<CB>::NTOP) window_kernel(const Jac<C>* in_t, const Jac<C>* in_w, int log_size, Jac<C>* win) {
-  using G = Geo<CB>;
-  __shared__ Jac<C> sh[256];
-  const int w = blockIdx.x, i = threadIdx.x;          // blockDim.x == NTOP
-  const Jac<C> T = in_t[(size_t)w * G::NTOP + i];
-  Jac<C> acc, ws = in_w[(size_t)w * G::NTOP + i];
-  jac::set_infinity<C>(acc);
-  // i * T by double-and-add over the bits of i
-#pragma unroll 1
-  for (int bit = G::LOG_NTOP - 1; bit >= 0; bit--) {
-    pt_dbl<C>(acc);
-    if ((i >> bit) & 1) pt_add<C>(acc, acc, T);
+// sum over a team of `count` lanes (a power of two, a multiple of 128) through sh[count / 2]: the upper half of the lanes
+// that are still active hands its values to the lower half
+template <class C>
+__device__ __forceinline__ void team_tree_sum(Jac<C>* sh, Jac<C>& v, int lane, int count) {
+  for (int half = count >> 1; half >= 1; half >>= 1) {
+    if (lane >= half && lane < 2 * half) sh[lane - half] = v;
+    __syncthreads();
+    if (lane < half) { const Jac<C> b = sh[lane]; pt_add<C>(v, v, b); }
+    __syncthreads();
   }
-  lds_tree_sum<C>(sh, acc, i, G::NTOP);
-  lds_tree_sum<C>(sh, ws, i, G::NTOP);
-  if (i == 0) {
+}
+// k * p by double-and-add over `bits` bits (k is lane-dependent: every lane executes every step)
+template <class C>
+__device__ __forceinline__ void small_multiple(Jac<C>& r, const Jac<C>& p, int k, int bits) {
+  jac::set_infinity<C>(r);
 #pragma unroll 1
-    for (int j = 0; j < log_size; j++) pt_dbl<C>(acc);
-    pt_add<C>(acc, acc, ws);
-    win[w] = acc;
+  for (int bit = bits - 1; bit >= 0; bit--) {
+    pt_dbl<C>(r);
+    if ((k >> bit) & 1) pt_add<C>(r, r, p);
+  }
+}
+constexpr int GROUP_NODES = 256, LOG_GROUP_NODES = 8;
+template <class C>
+__global__ void __launch_bounds__(3 * GROUP_NODES) group_kernel(const Jac<C>* in_t, const Jac<C>* in_w, Jac<C>* out) {
+  __shared__ Jac<C> sh[3][GROUP_NODES / 2];
+  const int team = threadIdx.x / GROUP_NODES, l = threadIdx.x % GROUP_NODES;      // teams are whole waves
+  const size_t node = (size_t)blockIdx.x * GROUP_NODES + l;
+  Jac<C> v;
+  if (team == 0) v = in_w[node];
+  else if (team == 1) v = in_t[node];
+  else { const Jac<C> t = in_t[node]; small_multiple<C>(v, t, l, LOG_GROUP_NODES); }
+  team_tree_sum<C>(sh[team], v, l, GROUP_NODES);
+  if (l == 0) out[(size_t)blockIdx.x * 3 + team] = v;
+}
+// per window: `ng` groups (a power of two, at most 256; teams are padded to a whole number of waves)
+template <class C>
+__global__ void __launch_bounds__(3 * 256) window_kernel(const Jac<C>* grp, int ng, int log_ng, int team_lanes, int log_size, Jac<C>* win) {
+  __shared__ Jac<C> sh[3][128];
+  const int w = blockIdx.x, team = threadIdx.x / team_lanes, g = threadIdx.x % team_lanes;     // blockDim.x == 3 * team_lanes
+  Jac<C> v;
+  jac::set_infinity<C>(v);
+  if (g < ng) {
+    const Jac<C> x = grp[((size_t)w * ng + g) * 3 + team];
+    if (team == 1) small_multiple<C>(v, x, g, log_ng);
+    else v = x;
+  }
+  team_tree_sum<C>(sh[team], v, g, team_lanes);
+  if (g == 0) sh[team][0] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Jac<C> r = sh[1][0];                           // P
+#pragma unroll 1
+    for (int j = 0; j < LOG_GROUP_NODES; j++) pt_dbl<C>(r);
+    pt_add<C>(r, r, sh[2][0]);                     // 256 P + Q
+#pragma unroll 1
+    for (int j = 0; j < log_size; j++) pt_dbl<C>(r);
+    pt_add<C>(r, r, sh[0][0]);                     // A + size (256 P + Q)
+    win[w] = r;
   }
 }
 // window sums of a further slab of terms are added to the running window sums
@@ -665,9 +817,10 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const Jac<C>* partial
   if (threadIdx.x == 0) win[0] = acc;                  // finish_kernel with nwin = 1 converts and stores it
 }
 
-// 5. Horner over the windows (`cbits` doublings per window), conversion to affine, output
+// 5. Horner over the windows (window w is `cbits` bits wide, the lowest `narrow` windows one bit less), conversion to
+//    affine, output
 template <class C>
-__global__ void __launch_bounds__(64) finish_kernel(const Jac<C>* win, int nwin, int cbits, u32* out, int out_fmt) {
+__global__ void __launch_bounds__(64) finish_kernel(const Jac<C>* win, int nwin, int cbits, int narrow, u32* out, int out_fmt) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   constexpr int NW = C::NW;
   using Fe = typename C::Fe;
@@ -675,7 +828,7 @@ __global__ void __launch_bounds__(64) finish_kernel(const Jac<C>* win, int nwin,
 #pragma unroll 1
   for (int w = nwin - 2; w >= 0; w--) {
 #pragma unroll 1
-    for (int j = 0; j < cbits; j++) pt_dbl<C>(r);
+    for (int j = (w < narrow) ? 1 : 0; j < cbits; j++) pt_dbl<C>(r);      // times 2^(width of window w)
     pt_add<C>(r, r, win[w]);
   }
   const bool inf = C::fe_is_zero(r.z);
@@ -704,7 +857,7 @@ __global__ void __launch_bounds__(256) to_affine_kernel(const u32* xyz, u32* xy,
 // Host side: all stages on c->stream out of one grow-only workspace.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef MSM_ROUNDS
-#define MSM_ROUNDS 4                 // bucket-sum runs per resident lane (ECGPU_MSM_ROUNDS)
+#define MSM_ROUNDS 6                 // bucket-sum runs per resident lane (ECGPU_MSM_ROUNDS)
 #endif
 static inline size_t msm_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static int msm_reserve(ecgpu_ctx* c, size_t need) {
@@ -749,15 +902,20 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
   const size_t sz_mag = al((size_t)NDIG * ms * sizeof(Mag)), sz_sgn = al(ms * 4);
   const size_t sz_bx = al(nb * sizeof(X)), sz_piece = al((size_t)ntask * sizeof(X)), sz_span = al((size_t)ntask * 4 + 8);
   const size_t n0 = nb / G::M;                         // nodes of the level that reads the buckets
-  const size_t sz_l0 = al(n0 * sizeof(J)), sz_l1 = al(n0 / G::M * sizeof(J)), sz_win = al(NWIN * sizeof(J));
+  const size_t sz_l0 = al(n0 * sizeof(J)), sz_l1 = al(n0 / G::M * sizeof(J)), sz_grp = al(n0 / GROUP_NODES * 3 * sizeof(J)), sz_win = al(NWIN * sizeof(J));
+  constexpr int NG = G::NG, LOG_NG = G::LOG_NG, TEAM = NG < 64 ? 64 : NG;        // lanes per team of the window kernel: whole waves
   // a run leaves at most two pieces (head and tail), so there are at most 2 ntask pieces: at most 2 ntask / SPAN_MAX buckets
   // over more than SPAN_MAX runs, cut into at most 2 ntask / HEAVY_CHUNK + one chunk each
   const size_t hmax = 2 * (size_t)ntask / SPAN_MAX + 1, cmax = 2 * (size_t)ntask / HEAVY_CHUNK + hmax + 1;
   const size_t sz_ctr = al(16), sz_heavy = al(hmax * sizeof(HeavyBucket)), sz_chunks = al(cmax * sizeof(HeavyChunk)), sz_partial = al(cmax * sizeof(J));
-  const size_t need = sz_aff + sz_prep + sz_mag + sz_sgn + sz_off + sz_coff + sz_tot + sz_part + 2 * sz_sorted + sz_bx + 2 * sz_piece + sz_span + 2 * sz_l0 + 2 * sz_l1 +
+  const size_t need = sz_aff + sz_prep + sz_mag + sz_sgn + sz_off + sz_coff + sz_tot + sz_part + 2 * sz_sorted + sz_bx + 2 * sz_piece + sz_span + 2 * sz_l0 + 2 * sz_l1 + sz_grp +
                       2 * sz_win + sz_ctr + sz_heavy + sz_chunks + sz_partial;
   int rc = msm_reserve(c, need);
   if (rc) return rc;
+  // the coarse scatter groups its tiles in more LDS than the 64 KB a kernel gets by default
+  static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&coarse_scatter_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         (int)sizeof(typename CoarseTile<CB>::Lds));
+  HIPCHK(c, lds_attr);
   char* p = (char*)c->msm_ws;
   u32* aff = (u32*)p; p += sz_aff;
   u32* prep = (u32*)p; p += sz_prep;
@@ -777,6 +935,7 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
   J* wa = (J*)p; p += sz_l0;
   J* tb = (J*)p; p += sz_l1;
   J* wb = (J*)p; p += sz_l1;
+  J* grp = (J*)p; p += sz_grp;
   J* win = (J*)p; p += sz_win;
   J* win_slab = (J*)p; p += sz_win;
   u32* ctr = (u32*)p; p += sz_ctr;                     // [0] buckets in pieces, [2] heavy buckets, [3] heavy chunks
@@ -800,8 +959,8 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
     hipLaunchKernelGGL(coarse_totals_kernel, dim3(cb_grid), dim3(256), 0, c->stream, (const u32*)part, NCB, G::NCOARSE, nch, tot);
     hipLaunchKernelGGL(coarse_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u32*)tot, NCB, coarse_off, offsets + nb);
     hipLaunchKernelGGL(coarse_cursors_kernel, dim3(cb_grid), dim3(256), 0, c->stream, part, NCB, G::NCOARSE, nch, (const u32*)coarse_off);
-    hipLaunchKernelGGL((coarse_scatter_kernel<CB>), dim3((unsigned)(NWIN * nch)), dim3(1024), 0, c->stream, (const Mag*)mag, (const u32*)sgn, cnt, ms, NHALF, CARRY_WIN, nch,
-                       (const u32*)part, mid, sorted);
+    hipLaunchKernelGGL((coarse_scatter_kernel<CB>), dim3((unsigned)(NWIN * nch)), dim3(1024), sizeof(typename CoarseTile<CB>::Lds), c->stream, (const Mag*)mag, (const u32*)sgn,
+                       cnt, ms, NHALF, CARRY_WIN, nch, (const u32*)part, mid, sorted);
     hipLaunchKernelGGL((fine_sort_kernel<CB>), dim3((unsigned)NCB), dim3(256), 0, c->stream, (const u32*)mid, (const u32*)coarse_off, CARRY_WIN, offsets, sorted);
     HIPCHK(c, hipMemsetAsync(ctr, 0, 16, c->stream));
     hipLaunchKernelGGL((bucket_sum_kernel<C, CB>), dim3(ntask / 256), dim3(256), 0, c->stream, (const u32*)prep, cnt, (const u32*)offsets, (const u32*)sorted, (int)nb, ntask,
@@ -812,22 +971,22 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
                        (const HeavyChunk*)chunks, (const X*)head, (const X*)tail, partial);
     hipLaunchKernelGGL((heavy_finish_kernel<C>), dim3((unsigned)c->num_cus), dim3(256), 0, c->stream, (const u32*)(ctr + 2), (const HeavyBucket*)heavy, (const J*)partial,
                        bucketsX);
-    // the tree: buckets -> nb / 8 nodes -> .. -> NTOP nodes per window -> window sums
+    // buckets -> nb / 8 nodes (-> / 8 for the wide windows) -> groups of 256 nodes -> window sums
     size_t nodes = n0;
-    hipLaunchKernelGGL((level0_kernel<C, CB>), dim3((unsigned)((nodes + 63) / 64)), dim3(64), 0, c->stream, (const X*)bucketsX, (const u32*)offsets, ta, wa, (int)nodes);
-    J *it = ta, *iw = wa, *ot = tb, *ow = wb;
     int log_size = G::LOG_M;
-    for (int lv = 1; lv < G::NLEVEL; lv++) {
+    J *it = ta, *iw = wa;
+    hipLaunchKernelGGL((level0_kernel<C, CB>), dim3((unsigned)((nodes + 63) / 64)), dim3(64), 0, c->stream, (const X*)bucketsX, (const u32*)offsets, ta, wa, (int)nodes);
+    for (int lv = 0; lv < G::NMID; lv++) {
       nodes /= G::M;
-      hipLaunchKernelGGL((level_kernel<C, CB>), dim3((unsigned)((nodes + 63) / 64)), dim3(64), 0, c->stream, (const J*)it, (const J*)iw, ot, ow, log_size, (int)nodes);
-      J* t = it; it = ot; ot = t;
-      t = iw; iw = ow; ow = t;
+      hipLaunchKernelGGL((level_kernel<C, CB>), dim3((unsigned)((nodes + 63) / 64)), dim3(64), 0, c->stream, (const J*)it, (const J*)iw, tb, wb, log_size, (int)nodes);
+      it = tb; iw = wb;
       log_size += G::LOG_M;
     }
-    hipLaunchKernelGGL((window_kernel<C, CB>), dim3(NWIN), dim3(G::NTOP), 0, c->stream, (const J*)it, (const J*)iw, log_size, wdst);
+    hipLaunchKernelGGL((group_kernel<C>), dim3((unsigned)(nodes / GROUP_NODES)), dim3(3 * GROUP_NODES), 0, c->stream, (const J*)it, (const J*)iw, grp);
+    hipLaunchKernelGGL((window_kernel<C>), dim3(NWIN), dim3(3 * TEAM), 0, c->stream, (const J*)grp, NG, LOG_NG, TEAM, log_size, wdst);
     if (s0 != 0) hipLaunchKernelGGL((windows_accumulate_kernel<C>), dim3(1), dim3(64), 0, c->stream, win, (const J*)win_slab, NWIN);
   }
-  hipLaunchKernelGGL((finish_kernel<C>), dim3(1), dim3(64), 0, c->stream, (const J*)win, (int)NWIN, CB, out, out_fmt);
+  hipLaunchKernelGGL((finish_kernel<C>), dim3(1), dim3(64), 0, c->stream, (const J*)win, (int)NWIN, CB, K::NARROW, out, out_fmt);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -835,7 +994,14 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
 // `mul` is the curve's batch scalar multiplication (used for small sums).
 // ECGPU_MSM_SMALL = 0 forces the bucket method for every size, ECGPU_MSM_CBITS = 16 | 19 one window width (both read per
 // call so that one process can exercise every path: measurements, tests of the bucket paths on small inputs).
-constexpr size_t WIDE_WINDOW_TERMS = (size_t)1 << 21;     // sums from this size on use 19-bit windows
+// 19-bit windows pay between these sizes (tools/msm_sizes.sh; ms at 16 / 19 bits - k256: 2^20 2.72 / 2.84, 2^21 3.96 / 3.90,
+// 2^22 6.34 / 6.17, 2^23 10.96 / 10.2, 2^24 20.06 / 20.17; p256: 2^21 4.98 / 5.51, 2^22 7.94 / 7.73, 2^23 12.93 / 12.33,
+// 2^24 22.96 / 23.48; p384: 2^21 18.1 / 19.1, 2^22 28.8 / 28.4): below, the eight times larger bucket tree costs more than
+// the bucket additions saved; from 2^24 terms on the 19-bit path needs two slabs (23-bit term index in a sorted entry)
+// where the 16-bit path needs one.
+constexpr size_t WIDE_WINDOW_MAX = (size_t)1 << 24;
+template <class C>
+constexpr size_t wide_window_min() { return C::A_IS_ZERO ? (size_t)1 << 21 : (size_t)1 << 22; }
 template <class C, class MulFn>
 static int msm_run(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt, MulFn mul) {
   constexpr int NW = C::NW;
@@ -857,13 +1023,13 @@ static int msm_run(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size
     if ((rc = mul(sc, pts, pt_fmt, prod, n))) return rc;
     hipLaunchKernelGGL((sum_affine_kernel<C>), dim3(blocks), dim3(256), 0, c->stream, (const u32*)prod, n, partial);
     hipLaunchKernelGGL((sum_partials_kernel<C>), dim3(1), dim3(256), 0, c->stream, (const J*)partial, blocks, win);
-    hipLaunchKernelGGL((finish_kernel<C>), dim3(1), dim3(64), 0, c->stream, (const J*)win, 1, 0, out, out_fmt);
+    hipLaunchKernelGGL((finish_kernel<C>), dim3(1), dim3(64), 0, c->stream, (const J*)win, 1, 0, 0, out, out_fmt);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
   const char* cb_env = getenv("ECGPU_MSM_CBITS");
   const int cb = cb_env ? atoi(cb_env) : 0;
-  const bool wide = (cb == 19) || (cb != 16 && n >= WIDE_WINDOW_TERMS);
+  const bool wide = (cb == 19) || (cb != 16 && n >= wide_window_min<C>() && n < WIDE_WINDOW_MAX);
   return wide ? msm_buckets<C, 19>(c, sc, pts, pt_fmt, n, out, out_fmt) : msm_buckets<C, 16>(c, sc, pts, pt_fmt, n, out, out_fmt);
 }
 

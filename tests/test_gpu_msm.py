@@ -58,7 +58,9 @@ def test_small_and_edge_cases(curve):
     cases.append(([7, 9], [G, None]))                           # identity point among the inputs
     cases.append(([2**16, 2**15, 2**15 - 1, 2**32 - 1, 2**255 % N], [synth.point(C, i, seed=61) for i in range(5)]))
     edge = [(N - 1) // 2, (N + 1) // 2, N - 1, N - 2, (N - 2**255) % N, 2**255 - 1, 2**255 + 1, N - 2**16, N - 2**15, N - 32767,
-            0x7FFF8000 << 224, (0x7FFF << 240) | ((1 << 240) - 1)]
+            0x7FFF8000 << 224, (0x7FFF << 240) | ((1 << 240) - 1),
+            # digit boundaries of the 18- / 19-bit windows: runs of ones that carry through every window, single bits at window edges
+            2**17, 2**18 - 1, 2**18, 2**18 + 1, 2**36 - 1, 2**72 - 1, 2**72, 2**110, 2**128 - 1, 2**128, 2**128 + 2**17, (1 << 200) - (1 << 17)]
     cases.append((edge, [synth.point(C, 50 + i, seed=61) for i in range(len(edge))]))
     ks = [rng.randrange(N) for _ in range(300)]
     cases.append((ks, [synth.point(C, i, seed=62) for i in range(300)]))
@@ -199,8 +201,9 @@ def test_nist_msm(cn, cid, path):
         G = (c.gx, c.gy)
         rng = random.Random(64 + cid)
         cases = [([5], [G]), ([0], [G]), ([n_ord - 1, 1], [G, G]), ([3, 3, 3], [G, G, G]), ([7, 9], [G, None]),
-                 ([(n_ord - 1) // 2, (n_ord + 1) // 2, n_ord - 2, 2**15, 2**16 - 1, 2**(8 * nb - 1) % n_ord, n_ord - 32768],
-                  [synth.point(c, i, seed=64) for i in range(7)]),
+                 ([(n_ord - 1) // 2, (n_ord + 1) // 2, n_ord - 2, 2**15, 2**16 - 1, 2**(8 * nb - 1) % n_ord, n_ord - 32768,
+                   2**17, 2**18 - 1, 2**18, 2**36 - 1, 2**180 - 1, 2**181, (n_ord - 1) // 2 - 2**17, n_ord - 2**18, 2**(8 * nb - 2) - 1, 2**(8 * nb - 2)],
+                  [synth.point(c, i, seed=64) for i in range(17)]),
                  ([rng.randrange(n_ord) for _ in range(200)], [synth.point(c, i, seed=65) for i in range(200)])]
         for ks, pts in cases:
             s = arr([M.i2b(c, k) for k in ks], nb)
