@@ -260,15 +260,27 @@ struct TileLds {
   u32 wtot[NT / 64];
   uint16_t key[TILE];
 };
+//   gcur (optional): cursors shared with other workgroups (global memory); a tile then reserves its room per key with
+//   one atomic instead of advancing L.cur
 template <int NKEY, int TILE, int NT, int PER>
-__device__ __forceinline__ void tile_scatter(TileLds<NKEY, TILE, NT>& L, const u32* e, u32* ks, u32* dst) {
+__device__ __forceinline__ void tile_scatter(TileLds<NKEY, TILE, NT>& L, const u32* e, u32* ks, u32* dst, u32* gcur = nullptr) {
   static_assert(PER * NT == TILE && NT % 64 == 0 && NKEY <= 0xFFFF, "tile shape");
   constexpr int KPT = (NKEY + NT - 1) / NT;                       // counters per thread in the scan
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // 1. count; the returned old value is the entry's slot within its key
+  // 1. count; the returned old value is the entry's slot within its key.  When every lane of the wave holds the same key
+  //    (equal scalars: a whole window in one bucket) one lane counts for all - 64 atomics on one address would serialise.
 #pragma unroll
-  for (int j = 0; j < PER; j++)
-    if (ks[j] != 0xFFFFu) ks[j] |= atomicAdd(&L.cnt[ks[j]], 1u) << 16;
+  for (int j = 0; j < PER; j++) {
+    const u32 k = ks[j];
+    const u32 k0 = __builtin_amdgcn_readfirstlane(k);
+    if (__builtin_expect(__all(k == k0) && k0 != 0xFFFFu, 0)) {
+      u32 base = 0;
+      if (lane == 0) base = atomicAdd(&L.cnt[k0], 64u);
+      ks[j] = k | ((__builtin_amdgcn_readfirstlane(base) + (u32)lane) << 16);
+    } else if (k != 0xFFFFu) {
+      ks[j] = k | (atomicAdd(&L.cnt[k], 1u) << 16);
+    }
+  }
   __syncthreads();
   // 2. exclusive scan of the counters: per thread, per wave (shuffles), across the waves (LDS)
   u32 v[KPT], local = 0;
@@ -283,7 +295,14 @@ __device__ __forceinline__ void tile_scatter(TileLds<NKEY, TILE, NT>& L, const u
 #pragma unroll 1
   for (int w = 0; w < wave; w++) run += L.wtot[w];
 #pragma unroll
-  for (int q = 0; q < KPT; q++) { const int k = tid * KPT + q; if (k < NKEY) { L.off[k] = run; run += v[q]; } }
+  for (int q = 0; q < KPT; q++) {
+    const int k = tid * KPT + q;
+    if (k < NKEY) {
+      L.off[k] = run;
+      run += v[q];
+      if (gcur && v[q]) L.cur[k] = atomicAdd(&gcur[k], v[q]);
+    }
+  }
   if (tid == NT - 1) L.off[NKEY] = run;
   __syncthreads();
   // 3. place
@@ -302,7 +321,7 @@ __device__ __forceinline__ void tile_scatter(TileLds<NKEY, TILE, NT>& L, const u
   __syncthreads();
   // 5. advance the cursors, clear the counters
 #pragma unroll
-  for (int q = 0; q < KPT; q++) { const int k = tid * KPT + q; if (k < NKEY) { L.cur[k] += v[q]; L.cnt[k] = 0; } }
+  for (int q = 0; q < KPT; q++) { const int k = tid * KPT + q; if (k < NKEY) { if (!gcur) L.cur[k] += v[q]; L.cnt[k] = 0; } }
   __syncthreads();
 }
 
@@ -362,32 +381,64 @@ struct FineTile {
   static constexpr int NT = 256, PER = 16, TILE = NT * PER;
   using Lds = TileLds<Geo<CB>::NFINE, TILE, NT>;
 };
+// A bin above BIG_BIN_TILES tiles (equal or clustered scalars: whole windows in a few buckets) would keep one workgroup busy
+// for milliseconds; it is only registered here and sorted by many workgroups, one tile each, with counters and cursors in
+// global memory (big_count / big_scan / big_place below).
+constexpr u32 BIG_BIN_TILES = 64;               // 2^18 entries; a uniform 2^24-term sum has 2^16 per bin
+// the fine keys of a tile counted into L.cnt (PER loads in flight per thread, then their LDS atomics)
+template <int CB, class L_t>
+__device__ __forceinline__ void fine_count_tile(L_t& L, const u32* mid, u32 t0, u32 hi) {
+  using G = Geo<CB>;
+  using T = FineTile<CB>;
+  const int t = threadIdx.x;
+  u32 v[T::PER];
+#pragma unroll
+  for (int r = 0; r < T::PER; r++) { const u32 i = t0 + (u32)r * T::NT + t; v[r] = (i < hi) ? mid[i] : 0xFFFFFFFFu; }
+#pragma unroll
+  for (int r = 0; r < T::PER; r++) {
+    const bool ok = t0 + (u32)r * T::NT + t < hi;
+    const u32 k = (v[r] >> G::INDEX_BITS) & (G::NFINE - 1), k0 = __builtin_amdgcn_readfirstlane(k);
+    if (__builtin_expect(__all(ok && k == k0), 0)) {         // one bucket for the whole wave (equal scalars): one atomic
+      if ((t & 63) == 0) atomicAdd(&L.cnt[k0], 64u);
+    } else if (ok) {
+      atomicAdd(&L.cnt[k], 1u);
+    }
+  }
+}
+// the entries of a tile and their fine keys, consecutive lanes reading consecutive entries
 template <int CB>
-__global__ void __launch_bounds__(256) fine_sort_kernel(const u32* mid, const u32* coarse_off, int carry_win, u32* offsets, u32* sorted) {
+__device__ __forceinline__ void fine_load_tile(const u32* mid, u32 t0, u32 hi, u32* e, u32* ks) {
+  using G = Geo<CB>;
+  using T = FineTile<CB>;
+#pragma unroll
+  for (int r = 0; r < T::PER; r++) {
+    const u32 i = t0 + (u32)r * T::NT + threadIdx.x;
+    const bool ok = i < hi;
+    e[r] = ok ? mid[i] : 0u;
+    ks[r] = ok ? ((e[r] >> G::INDEX_BITS) & (G::NFINE - 1)) : 0xFFFFu;
+  }
+}
+template <int CB>
+__global__ void __launch_bounds__(256) fine_sort_kernel(const u32* mid, const u32* coarse_off, int carry_win, u32* offsets, u32* sorted, u32* big_ctr, u32* big_list) {
   using G = Geo<CB>;
   using T = FineTile<CB>;
   constexpr int NFINE = G::NFINE;
   __shared__ typename T::Lds L;
   __shared__ u32 scn[NFINE];
-  // bins are taken from the top window down: its digits have fewer bits (14 of 19 for secp256k1), so its few occupied bins
-  // are the largest and must not be the last to start
-  const int j = (int)(gridDim.x - 1 - blockIdx.x), t = threadIdx.x;
+  const int j = blockIdx.x, t = threadIdx.x;            // low windows first: the narrow ones fill half their bins twice over
   const u32 lo = coarse_off[j], hi = coarse_off[j + 1];
   if (carry_win >= 0 && j >= carry_win * G::NCOARSE) {     // carry window: every entry of the bin is in its first bucket, already in place
     if (t < NFINE) offsets[(size_t)j * NFINE + t] = (t == 0) ? lo : hi;
     return;
   }
+  if (hi - lo > BIG_BIN_TILES * T::TILE) {
+    if (t == 0) big_list[atomicAdd(big_ctr, 1u)] = (u32)j;
+    return;
+  }
   if (t < NFINE) L.cnt[t] = 0;
   __syncthreads();
 #pragma unroll 1
-  for (u32 t0 = lo; t0 < hi; t0 += T::TILE) {                // PER loads in flight per thread, then their LDS atomics
-    u32 v[T::PER];
-#pragma unroll
-    for (int r = 0; r < T::PER; r++) { const u32 i = t0 + (u32)r * T::NT + t; v[r] = (i < hi) ? mid[i] : 0xFFFFFFFFu; }
-#pragma unroll
-    for (int r = 0; r < T::PER; r++)
-      if (t0 + (u32)r * T::NT + t < hi) atomicAdd(&L.cnt[(v[r] >> G::INDEX_BITS) & (NFINE - 1)], 1u);
-  }
+  for (u32 t0 = lo; t0 < hi; t0 += T::TILE) fine_count_tile<CB>(L, mid, t0, hi);
   __syncthreads();
   // exclusive scan of the NFINE counts
   if (t < NFINE) scn[t] = L.cnt[t];
@@ -409,14 +460,84 @@ __global__ void __launch_bounds__(256) fine_sort_kernel(const u32* mid, const u3
 #pragma unroll 1
   for (u32 t0 = lo; t0 < hi; t0 += T::TILE) {
     u32 e[T::PER], ks[T::PER];
-#pragma unroll
-    for (int r = 0; r < T::PER; r++) {
-      const u32 i = t0 + (u32)r * T::NT + t;                  // consecutive lanes read consecutive entries
-      const bool ok = i < hi;
-      e[r] = ok ? mid[i] : 0u;
-      ks[r] = ok ? ((e[r] >> G::INDEX_BITS) & (NFINE - 1)) : 0xFFFFu;
-    }
+    fine_load_tile<CB>(mid, t0, hi, e, ks);
     tile_scatter<NFINE, T::TILE, T::NT, T::PER>(L, e, ks, sorted);
+  }
+}
+// big bins, pass 1: every workgroup counts tiles of every registered bin into big_cnt[b][f]
+template <int CB>
+__global__ void __launch_bounds__(256) big_count_kernel(const u32* mid, const u32* coarse_off, const u32* big_ctr, const u32* big_list, u32* big_cnt) {
+  using G = Geo<CB>;
+  using T = FineTile<CB>;
+  constexpr int NFINE = G::NFINE;
+  __shared__ struct { u32 cnt[NFINE]; } L;
+  const int t = threadIdx.x;
+  const u32 nbig = *big_ctr;
+#pragma unroll 1
+  for (u32 b = 0; b < nbig; b++) {
+    const u32 j = big_list[b], lo = coarse_off[j], hi = coarse_off[j + 1];
+    const u32 ntile = (hi - lo + T::TILE - 1) / T::TILE;
+#pragma unroll 1
+    for (u32 s = blockIdx.x; s < ntile; s += gridDim.x) {
+      if (t < NFINE) L.cnt[t] = 0;
+      __syncthreads();
+      fine_count_tile<CB>(L, mid, lo + s * T::TILE, hi);
+      __syncthreads();
+      if (t < NFINE && L.cnt[t]) atomicAdd(&big_cnt[(size_t)b * NFINE + t], L.cnt[t]);
+      __syncthreads();
+    }
+  }
+}
+// pass 2: one workgroup per registered bin: bucket offsets and the shared cursors
+template <int CB>
+__global__ void __launch_bounds__(256) big_scan_kernel(const u32* coarse_off, const u32* big_ctr, const u32* big_list, const u32* big_cnt, u32* big_cur, u32* offsets) {
+  using G = Geo<CB>;
+  constexpr int NFINE = G::NFINE;
+  __shared__ u32 scn[NFINE];
+  const int t = threadIdx.x;
+  const u32 nbig = *big_ctr;
+#pragma unroll 1
+  for (u32 b = blockIdx.x; b < nbig; b += gridDim.x) {
+    const u32 j = big_list[b], lo = coarse_off[j];
+    const u32 c = (t < NFINE) ? big_cnt[(size_t)b * NFINE + t] : 0u;
+    if (t < NFINE) scn[t] = c;
+    __syncthreads();
+#pragma unroll 1
+    for (int off = 1; off < NFINE; off <<= 1) {
+      const u32 v = (t < NFINE && t >= off) ? scn[t - off] : 0u;
+      __syncthreads();
+      if (t < NFINE) scn[t] += v;
+      __syncthreads();
+    }
+    if (t < NFINE) {
+      const u32 start = lo + scn[t] - c;
+      big_cur[(size_t)b * NFINE + t] = start;
+      offsets[(size_t)j * NFINE + t] = start;
+    }
+    __syncthreads();
+  }
+}
+// pass 3: the tiles again, placed through the shared cursors
+template <int CB>
+__global__ void __launch_bounds__(256) big_place_kernel(const u32* mid, const u32* coarse_off, const u32* big_ctr, const u32* big_list, u32* big_cur, u32* sorted) {
+  using G = Geo<CB>;
+  using T = FineTile<CB>;
+  constexpr int NFINE = G::NFINE;
+  __shared__ typename T::Lds L;
+  const int t = threadIdx.x;
+  if (t < NFINE) L.cnt[t] = 0;
+  __syncthreads();
+  const u32 nbig = *big_ctr;
+#pragma unroll 1
+  for (u32 b = 0; b < nbig; b++) {
+    const u32 j = big_list[b], lo = coarse_off[j], hi = coarse_off[j + 1];
+    const u32 ntile = (hi - lo + T::TILE - 1) / T::TILE;
+#pragma unroll 1
+    for (u32 s = blockIdx.x; s < ntile; s += gridDim.x) {
+      u32 e[T::PER], ks[T::PER];
+      fine_load_tile<CB>(mid, lo + s * T::TILE, hi, e, ks);
+      tile_scatter<NFINE, T::TILE, T::NT, T::PER>(L, e, ks, sorted, big_cur + (size_t)b * NFINE);
+    }
   }
 }
 
@@ -907,9 +1028,12 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
   // a run leaves at most two pieces (head and tail), so there are at most 2 ntask pieces: at most 2 ntask / SPAN_MAX buckets
   // over more than SPAN_MAX runs, cut into at most 2 ntask / HEAVY_CHUNK + one chunk each
   const size_t hmax = 2 * (size_t)ntask / SPAN_MAX + 1, cmax = 2 * (size_t)ntask / HEAVY_CHUNK + hmax + 1;
+  // sort bins above BIG_BIN_TILES tiles: at most (entries of a slab) / (entries of such a bin) of them
+  const size_t maxbig = (size_t)NDIG * m / (BIG_BIN_TILES * FineTile<CB>::TILE) + 1;
+  const size_t sz_big = al(maxbig * 4) + 2 * al(maxbig * G::NFINE * 4);
   const size_t sz_ctr = al(16), sz_heavy = al(hmax * sizeof(HeavyBucket)), sz_chunks = al(cmax * sizeof(HeavyChunk)), sz_partial = al(cmax * sizeof(J));
   const size_t need = sz_aff + sz_prep + sz_mag + sz_sgn + sz_off + sz_coff + sz_tot + sz_part + 2 * sz_sorted + sz_bx + 2 * sz_piece + sz_span + 2 * sz_l0 + 2 * sz_l1 + sz_grp +
-                      2 * sz_win + sz_ctr + sz_heavy + sz_chunks + sz_partial;
+                      2 * sz_win + sz_ctr + sz_heavy + sz_chunks + sz_partial + sz_big;
   int rc = msm_reserve(c, need);
   if (rc) return rc;
   // the coarse scatter groups its tiles in more LDS than the 64 KB a kernel gets by default
@@ -938,10 +1062,13 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
   J* grp = (J*)p; p += sz_grp;
   J* win = (J*)p; p += sz_win;
   J* win_slab = (J*)p; p += sz_win;
-  u32* ctr = (u32*)p; p += sz_ctr;                     // [0] buckets in pieces, [2] heavy buckets, [3] heavy chunks
+  u32* ctr = (u32*)p; p += sz_ctr;                     // [0] buckets in pieces, [1] big sort bins, [2] heavy buckets, [3] heavy chunks
   HeavyBucket* heavy = (HeavyBucket*)p; p += sz_heavy;
   HeavyChunk* chunks = (HeavyChunk*)p; p += sz_chunks;
-  J* partial = (J*)p;
+  J* partial = (J*)p; p += sz_partial;
+  u32* big_cnt = (u32*)p; p += al(maxbig * G::NFINE * 4);          // zeroed together with the list behind it: see the memset below
+  u32* big_list = (u32*)p; p += al(maxbig * 4);
+  u32* big_cur = (u32*)p;
   const size_t pin = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * (size_t)NW;      // 32-bit words per input point
   const unsigned cb_grid = (unsigned)((NCB + 255) / 256);
   for (size_t s0 = 0; s0 < n; s0 += slab) {
@@ -961,8 +1088,16 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
     hipLaunchKernelGGL(coarse_cursors_kernel, dim3(cb_grid), dim3(256), 0, c->stream, part, NCB, G::NCOARSE, nch, (const u32*)coarse_off);
     hipLaunchKernelGGL((coarse_scatter_kernel<CB>), dim3((unsigned)(NWIN * nch)), dim3(1024), sizeof(typename CoarseTile<CB>::Lds), c->stream, (const Mag*)mag, (const u32*)sgn,
                        cnt, ms, NHALF, CARRY_WIN, nch, (const u32*)part, mid, sorted);
-    hipLaunchKernelGGL((fine_sort_kernel<CB>), dim3((unsigned)NCB), dim3(256), 0, c->stream, (const u32*)mid, (const u32*)coarse_off, CARRY_WIN, offsets, sorted);
     HIPCHK(c, hipMemsetAsync(ctr, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(big_cnt, 0, al(maxbig * G::NFINE * 4), c->stream));
+    hipLaunchKernelGGL((fine_sort_kernel<CB>), dim3((unsigned)NCB), dim3(256), 0, c->stream, (const u32*)mid, (const u32*)coarse_off, CARRY_WIN, offsets, sorted, ctr + 1,
+                       big_list);
+    hipLaunchKernelGGL((big_count_kernel<CB>), dim3((unsigned)c->num_cus * 4), dim3(256), 0, c->stream, (const u32*)mid, (const u32*)coarse_off, (const u32*)(ctr + 1),
+                       (const u32*)big_list, big_cnt);
+    hipLaunchKernelGGL((big_scan_kernel<CB>), dim3(64), dim3(256), 0, c->stream, (const u32*)coarse_off, (const u32*)(ctr + 1), (const u32*)big_list, (const u32*)big_cnt,
+                       big_cur, offsets);
+    hipLaunchKernelGGL((big_place_kernel<CB>), dim3((unsigned)c->num_cus * 4), dim3(256), 0, c->stream, (const u32*)mid, (const u32*)coarse_off, (const u32*)(ctr + 1),
+                       (const u32*)big_list, big_cur, sorted);
     hipLaunchKernelGGL((bucket_sum_kernel<C, CB>), dim3(ntask / 256), dim3(256), 0, c->stream, (const u32*)prep, cnt, (const u32*)offsets, (const u32*)sorted, (int)nb, ntask,
                        bucketsX, head, tail, ctr, span_list);
     hipLaunchKernelGGL((span_combine_kernel<C, CB>), dim3(ecgpu_grid_for(c, ntask, 8)), dim3(256), 0, c->stream, (const u32*)offsets, (int)nb, ntask, (const u32*)ctr,

@@ -10,7 +10,11 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 last = max(i for i, r in enumerate(rows) if "digits_kernel" in r["Kernel_Name"])
 t0 = int(rows[last]["Start_Timestamp"])
 end = 0
+prev = ""
 for r in rows[last:]:
+    if end and "msm::finish_kernel" in prev:
+        break
+    prev = r["Kernel_Name"]
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     end = max(end, e)
     name = r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1].replace("void ", "")[:28]
