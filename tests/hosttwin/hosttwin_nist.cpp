@@ -125,7 +125,7 @@ extern "C" int ht_vb_mul(int curve, const uint8_t* scalars, const uint8_t* point
 }
 
 // ---- XYZZ bucket accumulator of the MSM (msm.hpp) over any curve: p (X||Y||ZZ||ZZZ) += q (affine x||y), converted to the
-//      Jacobian triple the reduction tree works on; out = X||Y||Z
+//      Jacobian triple the reduction tree works on (odd entries: and back to XYZZ and forth once more); out = X||Y||Z
 #include "msm.hpp"
 template <class C>
 static int xyzz_op(const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
@@ -136,6 +136,11 @@ static int xyzz_op(const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
     msm::xyzz_add_mixed<C>(a, x, y);
     Jac<C> r;
     msm::xyzz_to_jacobian<C>(r, a);
+    if (i & 1) {                                  // odd entries also go through the way back, as the folded bucket pieces do
+      msm::Xyzz<C> b;
+      msm::jacobian_to_xyzz<C>(b, r);
+      msm::xyzz_to_jacobian<C>(r, b);
+    }
     store_jac<C>(out + 3 * C::NB * i, r);
   }
   return 0;
