@@ -63,8 +63,8 @@ WORK = {
     #   loop    : 128 dbl (3M+4S) + 66 * 15/16 mixed adds (8M+3S)                                      = 879M + 697.6S
     #   output  : 2M (global Z) + batched normalise 6M+1S + (255S+15M)/32                              =   9M +   9S
     "k256_varbase_fast": (87 + 128 * 3 + 66 * 15 / 16 * 8 + 9, 29 + 128 * 4 + 66 * 15 / 16 * 3 + 9),
-    # 13 signed 20-bit windows: 12 mixed additions (the first is a copy) + normalise 6M+1S + (255S+12M)/64
-    "p256_fixedbase": (12 * 8 + 6 + 12 / 64, 12 * 3 + 1 + 255 / 64),
+    # 11 signed 24-bit windows (5.9 GB table): 10 mixed additions (the first is a copy) + normalise 6M+1S + (255S+12M)/64
+    "p256_fixedbase": (10 * 8 + 6 + 12 / 64, 10 * 3 + 1 + 255 / 64),
     # 96 windows x 4 doublings (4M+4S) + 89 mixed additions (97 digits x 15/16, first one a copy) + table (4 dbl,
     # 3 general additions 11M+5S) + table to affine 8 x (6M+1S) + (385S+14M)/8 + output normalise 6M+1S + (385S+14M)/8
     "p384_varbase": (1536 + 89 * 8 + 49 + 48 + 14 / 8 + 6 + 14 / 8, 1536 + 89 * 3 + 31 + 8 + 385 / 8 + 1 + 385 / 8),
@@ -72,7 +72,7 @@ WORK = {
     # per-term share of the endomorphism (1M), of the bucket pieces and of the bucket reduction (1.8 M buckets: XYZZ -> Jacobian
     # and two general additions 12M+4S each; 1.5 M pieces folded) ~ 9M + 3S
     "k256_msm": (14 * 8 + 1 + 9, 14 * 2 + 3),
-    # verification = u2 Q (headline kernel) + u1 G (20-bit table) + prep / check (57 scalar-field equivalents + 7)
+    # verification = u2 Q (headline kernel) + u1 G (20-bit table at this batch size) + prep / check (57 scalar-field equivalents + 7)
     "k256_ecdsa_verify": (87 + 128 * 3 + 66 * 15 / 16 * 8 + 9 + 12 * 8 + 6 + 64, 29 + 128 * 4 + 66 * 15 / 16 * 3 + 9 + 12 * 3 + 5),
     # p256 verification = u2 Q (vb::mul_kernel<CurveP256,8,4>: 256 doublings 4M+4S, 60 general additions 11M+5S, table 4 dbl + 3 add,
     # output normalise 6M+1S + (255S+12M)/8 = 1 740 M + 1 388 S) + u1 G (20-bit table: 102 M + 41 S) + prep / check (~64 M)
@@ -84,7 +84,7 @@ WORKLOADS = {
                          bytes_per_unit=32 + 64 + 65, kernel="k256_mul_fast_kernel<32,4>", pmc_match="k256_mul_fast_kernel",
                          desc="k256 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
     "p256_fixedbase": dict(curve="p256", cid=1, log2n=24, fixed=True, msm=False, metric="p256 fixed-base (mul_by_generator) scalar-muls/sec", unit="scalar-muls/s",
-                           bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,20,64,4>", pmc_match="mul_wide_kernel",
+                           bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,24,64,4>", pmc_match="mul_wide_kernel",
                            desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
     "p384_varbase": dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
                          bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,4>", pmc_match="vb::mul_kernel",

@@ -77,13 +77,18 @@ struct CurveOps {
     return 0;
   }
   // wide tables TW[j][d-1] = d 2^(WB j) G, 2^(WB-1) entries per window, built by multiplying the scalars d 2^(WB j)
-  // with the 8-bit-window kernel; used for large batches, where the build cost (one pass over 0.56 M points for
-  // WB = 16, 6.8 M for WB = 20) is amortised
+  // with the 8-bit-window kernel (WB <= 20) or the 20-bit-window kernel (WB > 20); used for large batches, where the
+  // build cost (one pass over 0.56 M points for WB = 16, 6.8 M for WB = 20, 92 M for WB = 24, 336 M for WB = 26) is
+  // amortised.  The 288 GB of HBM are what makes the last two possible: every window bit less is one mixed addition of
+  // twelve saved per result, paid for with table bytes that a lane reads one 64-byte entry at a time.
   template <int WB>
   static int ensure_fb_wide_table(ecgpu_ctx* c, void** slot) {
     if (*slot) return 0;
     int rc = ensure_fb_table(c);
     if (rc) return rc;
+    if constexpr (WB > 20) {
+      if ((rc = ensure_fb_wide_table<20>(c, &c->fb20_table[C::ID]))) return rc;
+    }
     const size_t total = (size_t)fb::nwin_wide<C, WB>() * fb::wide_entries<WB>();
     struct Tmp {                       // released on every exit path
       void* p = nullptr;
@@ -94,8 +99,12 @@ struct CurveOps {
     HIPCHK(c, hipMalloc(&ttab.p, total * sizeof(AffEntry<C>)));
     void *ks = tks.p, *xy = txy.p, *tab = ttab.p;
     hipLaunchKernelGGL((fb::table_scalars_kernel<C, WB>), dim3(ecgpu_grid_for(c, total, 8)), dim3(256), 0, c->stream, (u32*)ks, total);
-    hipLaunchKernelGGL((fb::mul_kernel<C, 16, 4>), dim3(ecgpu_grid_for(c, total, 4)), dim3(256), 0, c->stream, (const u32*)ks,
-                       (const AffEntry<C>*)c->fb_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, total);
+    if constexpr (WB > 20)
+      hipLaunchKernelGGL((fb::mul_wide_kernel<C, 20, FB_BATCH, 4>), dim3(ecgpu_grid_for(c, total, 4)), dim3(256), 0, c->stream, (const u32*)ks,
+                         (const AffEntry<C>*)c->fb20_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, total);
+    else
+      hipLaunchKernelGGL((fb::mul_kernel<C, 16, 4>), dim3(ecgpu_grid_for(c, total, 4)), dim3(256), 0, c->stream, (const u32*)ks,
+                         (const AffEntry<C>*)c->fb_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, total);
     hipLaunchKernelGGL((fb::table_from_bytes_kernel<C>), dim3(ecgpu_grid_for(c, total, 8)), dim3(256), 0, c->stream, (const u32*)xy,
                        (AffEntry<C>*)tab, total);
     HIPCHK(c, hipGetLastError());
@@ -104,26 +113,24 @@ struct CurveOps {
     ttab.p = nullptr;                  // the context owns the table now; the two scratch buffers go with this scope
     return 0;
   }
+  template <int WB>
+  static int mul_gen_wide(ecgpu_ctx* c, void** slot, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
+    int rc = ensure_fb_wide_table<WB>(c, slot);
+    if (rc) return rc;
+    hipLaunchKernelGGL((fb::mul_wide_kernel<C, WB, FB_BATCH, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)*slot, out, out_fmt,
+                       out_inf, n);
+    HIPCHK(c, hipGetLastError());
+    return 1;
+  }
   static int mul_gen_fast(ecgpu_ctx* c, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
-    int rc;
-    // ECGPU_FB_WINDOW = 8 / 16 / 20 forces one table (measurements); default by batch size
+    // ECGPU_FB_WINDOW = 8 / 16 / 20 / 24 / 26 forces one table (measurements; 26 is never chosen by size); default by batch size
     static const int forced = [] { const char* e = getenv("ECGPU_FB_WINDOW"); return e ? atoi(e) : 0; }();
-    const int wb = forced ? forced : (n >= ((size_t)1 << 21) ? 20 : n >= ((size_t)1 << 18) ? 16 : 8);
-    if (wb == 20) {
-      if ((rc = ensure_fb_wide_table<20>(c, &c->fb20_table[C::ID]))) return rc;
-      hipLaunchKernelGGL((fb::mul_wide_kernel<C, 20, FB_BATCH, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
-                         (const AffEntry<C>*)c->fb20_table[C::ID], out, out_fmt, out_inf, n);
-      HIPCHK(c, hipGetLastError());
-      return 1;
-    }
-    if (wb == 16) {
-      if ((rc = ensure_fb_wide_table<16>(c, &c->fb16_table[C::ID]))) return rc;
-      hipLaunchKernelGGL((fb::mul_wide_kernel<C, 16, FB_BATCH, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
-                         (const AffEntry<C>*)c->fb16_table[C::ID], out, out_fmt, out_inf, n);
-      HIPCHK(c, hipGetLastError());
-      return 1;
-    }
-    rc = ensure_fb_table(c);
+    const int wb = forced ? forced : (n >= ((size_t)1 << 23) ? 24 : n >= ((size_t)1 << 21) ? 20 : n >= ((size_t)1 << 18) ? 16 : 8);
+    if (wb == 26) return mul_gen_wide<26>(c, &c->fb26_table[C::ID], sc, out, out_fmt, out_inf, n);
+    if (wb == 24) return mul_gen_wide<24>(c, &c->fb24_table[C::ID], sc, out, out_fmt, out_inf, n);
+    if (wb == 20) return mul_gen_wide<20>(c, &c->fb20_table[C::ID], sc, out, out_fmt, out_inf, n);
+    if (wb == 16) return mul_gen_wide<16>(c, &c->fb16_table[C::ID], sc, out, out_fmt, out_inf, n);
+    int rc = ensure_fb_table(c);
     if (rc) return rc;
     hipLaunchKernelGGL((fb::mul_kernel<C, 16, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
                        (const AffEntry<C>*)c->fb_table[C::ID], out, out_fmt, out_inf, n);

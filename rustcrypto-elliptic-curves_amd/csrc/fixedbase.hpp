@@ -23,6 +23,10 @@ template <class C> constexpr int nwin() { return C::NB + 1; }            // one 
 // wide variants: WB-bit windows, 2^(WB-1) entries per window, 8 NB / WB additions.
 //   WB = 16: 17 x 2^15 entries (36 MB per 256-bit curve, served from the Infinity Cache)      - batches >= 2^18
 //   WB = 20: 13 x 2^19 entries (436 MB per 256-bit curve, 1 GB for p384, HBM-resident gathers) - batches >= 2^21
+//   WB = 24: 11 x 2^23 entries (5.9 GB per 256-bit curve, 13.7 GB for p384; built in ~30 ms)  - batches >= 2^23
+//   WB = 26: 10 x 2^25 entries (21.5 GB per 256-bit curve; built in ~1.3 s)                     - ECGPU_FB_WINDOW=26 only
+//   (p256, 2^24 results: 16.1 / 14.2 / 13.1 ms with WB = 20 / 24 / 26 - every addition a window saves is 11 of ~140
+//   multiplications, and the gathers from a table no cache holds stay hidden behind them)
 // When WB divides the scalar width the signed recoding can carry out of the top window (one extra window that only
 // ever sees digit 1); otherwise the top window has spare bits and absorbs the carry.
 template <int WB> constexpr int wide_entries() { return 1 << (WB - 1); }
