@@ -705,18 +705,12 @@ __global__ void __launch_bounds__(256) span_combine_kernel(const u32* offsets, i
   }
 }
 
-// sum over the lanes of a workgroup through LDS (sh holds 256 points; count = 256 or 512 lanes)
+// sum over the 256 lanes of a workgroup through LDS
 template <class C>
 __device__ __forceinline__ void lds_tree_sum(Jac<C>* sh, Jac<C>& v, int lane, int count) {
-  if (count == 512) {                             // fold the upper half first
-    if (lane >= 256) sh[lane - 256] = v;
-    __syncthreads();
-    if (lane < 256) { Jac<C> b = sh[lane]; pt_add<C>(v, v, b); }
-    __syncthreads();
-  }
-  if (lane < 256) sh[lane] = v;
+  sh[lane] = v;
   __syncthreads();
-  for (int off = 128; off >= 1; off >>= 1) {
+  for (int off = count >> 1; off >= 1; off >>= 1) {
     if (lane < off) {
       Jac<C> a = sh[lane], b = sh[lane + off];
       pt_add<C>(a, a, b);
@@ -1078,10 +1072,10 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
                       2 * sz_win + sz_ctr + sz_heavy + sz_chunks + sz_partial + sz_big;
   int rc = msm_reserve(c, need);
   if (rc) return rc;
-  // the coarse scatter groups its tiles in more LDS than the 64 KB a kernel gets by default
-  static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&coarse_scatter_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                         (int)sizeof(typename CoarseTile<CB>::Lds));
-  HIPCHK(c, lds_attr);
+  // the coarse scatter groups its tiles in more LDS than the 64 KB a kernel gets by default (set per call: the attribute
+  // belongs to the function on the current device, and a process may hold contexts on several devices)
+  HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&coarse_scatter_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sizeof(typename CoarseTile<CB>::Lds)));
   char* p = (char*)c->msm_ws;
   u32* aff = (u32*)p; p += sz_aff;
   u32* prep = (u32*)p; p += sz_prep;
