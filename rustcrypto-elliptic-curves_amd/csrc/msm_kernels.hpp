@@ -891,11 +891,12 @@ __global__ void __launch_bounds__(64) windows_accumulate_kernel(Jac<C>* total, c
   if (w < nwin) { Jac<C> a = total[w]; pt_add<C>(a, a, slab[w]); total[w] = a; }
 }
 
-// Small sums (n below SMALL_MSM_TERMS): the bucket method has a fixed cost of ~2 ms (the buckets to reduce, the serial
+// Small sums (n below SMALL_MSM_TERMS): the bucket method has a fixed cost of ~1.3 ms (the buckets to reduce, the serial
 // doublings), more than n plain scalar multiplications take, so those run through the variable-base kernel and
 // the n products are summed here: one workgroup per slice (lanes stride, LDS tree), then one workgroup over the slice
-// sums.  Measured on k256 (ms, this path / buckets): 2^10 1.1 / 2.2, 2^14 1.2 / 2.3, 2^16 1.3 / 2.5, 2^18 3.1 / 2.9.
-constexpr size_t SMALL_MSM_TERMS = (size_t)3 << 16;
+// sums.  Measured (ms, this path / 16-bit buckets) - k256: 2^12 1.06 / 1.54, 2^14 1.11 / 1.30, 2^16 1.21 / 1.31,
+// 2^17 1.86 / 1.40; p256: 2^14 1.92 / 2.32, 2^16 2.08 / 2.56, 2^17 3.39 / 2.34.
+constexpr size_t SMALL_MSM_TERMS = (size_t)5 << 14;
 template <class C>
 __global__ void __launch_bounds__(256) sum_affine_kernel(const u32* xy, size_t n, Jac<C>* partial) {
   __shared__ Jac<C> sh[256];

@@ -14,7 +14,7 @@ N = C.n
 
 
 def _set_path(path):
-    """"auto": the library's own choice (below 3 * 2^16 terms: n scalar multiplications and a tree sum; 16-bit windows
+    """"auto": the library's own choice (below 5 * 2^14 terms: n scalar multiplications and a tree sum; 16-bit windows
     below 2^21 terms, 19-bit windows from there on); "buckets16" / "buckets19": the bucket method with that window width
     forced for all sizes (ECGPU_MSM_SMALL=0, ECGPU_MSM_CBITS: both read per call)."""
     import os

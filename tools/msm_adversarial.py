@@ -34,8 +34,8 @@ for name, k in (("all ones (a plain sum of points)", 1), ("all n - 1", c.n - 1),
     os.environ.pop("ECGPU_MSM_SMALL")
     ones = torch.zeros((n, 32), dtype=torch.uint8, device="cuda"); ones[:, 31] = 1
     parts = []
-    for lo in range(0, n, 1 << 17):                      # chunks below the small-path threshold
-        hi = min(n, lo + (1 << 17))
+    for lo in range(0, n, 1 << 16):                      # chunks below the small-path threshold
+        hi = min(n, lo + (1 << 16))
         t = torch.empty((64,), dtype=torch.uint8, device="cuda")
         cv.msm_device(ones[lo:hi], d_p[lo:hi], hi - lo, t)
         parts.append(t)
