@@ -112,3 +112,40 @@ def test_k256_config2_2p24_second_pass():
         return [(3, 0, 5, "zero"), (17, 0, 77, "ident"), (31, 0, lanes - 1, "n-1"), (9, 0, 64, "n+3"),
                 (30, 1, 77, "zero"), (2, 1, 12345, "ident"), (31, 1, lanes - 1, "n-1"), (0, 1, 0, "n+3")]
     assert _run_varbase("k256", 0, 1 << 24, 60_000_000, edges) >= 32768 + 8192
+
+
+@pytest.mark.parametrize("cname,cid,n,first", [
+    ("k256", 0, 1 << 23, 5),                       # BASELINE config 4, one GPU's share: 19-bit windows, one slab
+    ("k256", 0, (1 << 24) + 777, 1 << 30),         # 16-bit windows, two slabs (24-bit term index), the second one tiny
+    ("p256", 1, 1 << 22, 9),                       # 19-bit windows without the endomorphism (14 windows)
+])
+def test_msm_full_sizes_structured(cname, cid, n, first):
+    """The MSM at sizes no term-by-term oracle reaches: P_i = (a0 + i d) G (computed on the device by the fixed-base path),
+    seeded scalars, and the closed form (sum k_i (a0 + i d) mod n) G of SURVEY.md section 8d - over ALL terms, with a
+    zero scalar, a scalar n - 1 and an identity point planted (the identity's term drops out of the closed form)."""
+    import torch
+    import ecgpu
+    import bench
+    c = {0: synth.M.K256, 1: synth.M.P256}[cid]
+    ctx = ecgpu.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    cv = ctx.curve(cname)
+    ps = bench.structured_point_scalars(first, n)
+    d_pts = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    cv.mul_device(torch.from_numpy(ps).cuda(), None, d_pts, n)
+    d_s = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_s, n, synth.SEED, first)
+    ctx.synchronize()
+    d_s[12345] = 0
+    d_s[n - 7] = torch.from_numpy(np.frombuffer((c.n - 1).to_bytes(32, "big"), dtype=np.uint8).copy()).cuda()
+    d_pts[n // 2 + 1] = 0
+    torch.cuda.synchronize()
+    d_out = torch.empty((64,), dtype=torch.uint8, device="cuda")
+    cv.msm_device(d_s, d_pts, n, d_out)
+    ctx.synchronize()
+    ks = d_s.cpu().numpy()
+    ks[n // 2 + 1] = 0                             # the identity point contributes nothing
+    tot = bench.msm_expected_scalar(ks, first, c.n)
+    want = synth.M.affine_mul(c, tot, (c.gx, c.gy))
+    assert bytes(d_out.cpu().numpy()) == synth.M.i2b(c, want[0]) + synth.M.i2b(c, want[1])
+    ctx.close()
