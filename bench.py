@@ -63,8 +63,8 @@ WORK = {
     #   loop    : 128 dbl (3M+4S) + 66 * 15/16 mixed adds (8M+3S)                                      = 879M + 697.6S
     #   output  : 2M (global Z) + batched normalise 6M+1S + (255S+15M)/32                              =   9M +   9S
     "k256_varbase_fast": (87 + 128 * 3 + 66 * 15 / 16 * 8 + 9, 29 + 128 * 4 + 66 * 15 / 16 * 3 + 9),
-    # 11 signed 24-bit windows (5.9 GB table): 10 mixed additions (the first is a copy) + normalise 6M+1S + (255S+12M)/64
-    "p256_fixedbase": (10 * 8 + 6 + 12 / 64, 10 * 3 + 1 + 255 / 64),
+    # 10 signed 26-bit windows (21.5 GB table): 9 mixed additions (the first is a copy) + normalise 6M+1S + (255S+12M)/64
+    "p256_fixedbase": (9 * 8 + 6 + 12 / 64, 9 * 3 + 1 + 255 / 64),
     # 96 windows x 4 doublings (4M+4S) + 89 mixed additions (97 digits x 15/16, first one a copy) + table (4 dbl,
     # 3 general additions 11M+5S) + table to affine 8 x (6M+1S) + (385S+14M)/8 + output normalise 6M+1S + (385S+14M)/8
     "p384_varbase": (1536 + 89 * 8 + 49 + 48 + 14 / 8 + 6 + 14 / 8, 1536 + 89 * 3 + 31 + 8 + 385 / 8 + 1 + 385 / 8),
@@ -84,7 +84,7 @@ WORKLOADS = {
                          bytes_per_unit=32 + 64 + 65, kernel="k256_mul_fast_kernel<32,4>", pmc_match="k256_mul_fast_kernel",
                          desc="k256 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
     "p256_fixedbase": dict(curve="p256", cid=1, log2n=24, fixed=True, msm=False, metric="p256 fixed-base (mul_by_generator) scalar-muls/sec", unit="scalar-muls/s",
-                           bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,24,64,4>", pmc_match="mul_wide_kernel",
+                           bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,26,64,4>", pmc_match="mul_wide_kernel",
                            desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
     "p384_varbase": dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
                          bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,4>", pmc_match="vb::mul_kernel",

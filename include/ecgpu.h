@@ -101,9 +101,10 @@ enum {
 
 /* ---- context ------------------------------------------------------------------------------
  * A context owns grow-only workspaces and, per curve, the generator tables it has needed so far (built on the device on
- * first use, kept until ecgpu_destroy): 270 KB for batches below 2^18, 36 MB from 2^18, 436 MB from 2^21 and 5.9 GB
- * (13.7 GB for P-384) from 2^23 results per call; the first call of a size class pays the build (7 ms / 30 ms for the last
- * two).  ECGPU_FB_WINDOW in the environment pins one table width. */
+ * first use, kept until ecgpu_destroy): 270 KB for batches below 2^18, 36 MB from 2^18, 436 MB from 2^21, 5.9 GB
+ * (13.7 GB for P-384) from 2^23 and 21.5 GB (secp256k1, P-256) from 2^24 results per call; the first call of a size class
+ * pays the build (7 / 30 / 85 ms for the last three).  In the environment ECGPU_FB_MAX_WINDOW = 8 | 16 | 20 | 24 | 26 caps
+ * the table width a context may build, ECGPU_FB_WINDOW pins one. */
 int ecgpu_create(ecgpu_ctx** ctx, int device_index);
 void ecgpu_destroy(ecgpu_ctx* ctx);
 /* Use the caller's HIP stream (hipStream_t) for all launches; NULL = the context's own stream.  Calls on one context

@@ -90,23 +90,27 @@ struct CurveOps {
       if ((rc = ensure_fb_wide_table<20>(c, &c->fb20_table[C::ID]))) return rc;
     }
     const size_t total = (size_t)fb::nwin_wide<C, WB>() * fb::wide_entries<WB>();
+    const size_t chunk = total < ((size_t)1 << 24) ? total : ((size_t)1 << 24);     // entries per pass: at most 1.5 GB (2.3 GB for p384) of scratch
     struct Tmp {                       // released on every exit path
       void* p = nullptr;
       ~Tmp() { if (p) (void)hipFree(p); }
     } tks, txy, ttab;
-    HIPCHK(c, hipMalloc(&tks.p, total * C::NB));
-    HIPCHK(c, hipMalloc(&txy.p, total * 2 * C::NB));
+    HIPCHK(c, hipMalloc(&tks.p, chunk * C::NB));
+    HIPCHK(c, hipMalloc(&txy.p, chunk * 2 * C::NB));
     HIPCHK(c, hipMalloc(&ttab.p, total * sizeof(AffEntry<C>)));
-    void *ks = tks.p, *xy = txy.p, *tab = ttab.p;
-    hipLaunchKernelGGL((fb::table_scalars_kernel<C, WB>), dim3(ecgpu_grid_for(c, total, 8)), dim3(256), 0, c->stream, (u32*)ks, total);
-    if constexpr (WB > 20)
-      hipLaunchKernelGGL((fb::mul_wide_kernel<C, 20, FB_BATCH, 4>), dim3(ecgpu_grid_for(c, total, 4)), dim3(256), 0, c->stream, (const u32*)ks,
-                         (const AffEntry<C>*)c->fb20_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, total);
-    else
-      hipLaunchKernelGGL((fb::mul_kernel<C, 16, 4>), dim3(ecgpu_grid_for(c, total, 4)), dim3(256), 0, c->stream, (const u32*)ks,
-                         (const AffEntry<C>*)c->fb_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, total);
-    hipLaunchKernelGGL((fb::table_from_bytes_kernel<C>), dim3(ecgpu_grid_for(c, total, 8)), dim3(256), 0, c->stream, (const u32*)xy,
-                       (AffEntry<C>*)tab, total);
+    void *ks = tks.p, *xy = txy.p;
+    AffEntry<C>* tab = (AffEntry<C>*)ttab.p;
+    for (size_t e0 = 0; e0 < total; e0 += chunk) {
+      const size_t cnt = total - e0 < chunk ? total - e0 : chunk;
+      hipLaunchKernelGGL((fb::table_scalars_kernel<C, WB>), dim3(ecgpu_grid_for(c, cnt, 8)), dim3(256), 0, c->stream, (u32*)ks, e0, cnt);
+      if constexpr (WB > 20)
+        hipLaunchKernelGGL((fb::mul_wide_kernel<C, 20, FB_BATCH, 4>), dim3(ecgpu_grid_for(c, cnt, 4)), dim3(256), 0, c->stream, (const u32*)ks,
+                           (const AffEntry<C>*)c->fb20_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, cnt);
+      else
+        hipLaunchKernelGGL((fb::mul_kernel<C, 16, 4>), dim3(ecgpu_grid_for(c, cnt, 4)), dim3(256), 0, c->stream, (const u32*)ks,
+                           (const AffEntry<C>*)c->fb_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, cnt);
+      hipLaunchKernelGGL((fb::table_from_bytes_kernel<C>), dim3(ecgpu_grid_for(c, cnt, 8)), dim3(256), 0, c->stream, (const u32*)xy, tab + e0, cnt);
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *slot = tab;
@@ -123,9 +127,14 @@ struct CurveOps {
     return 1;
   }
   static int mul_gen_fast(ecgpu_ctx* c, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
-    // ECGPU_FB_WINDOW = 8 / 16 / 20 / 24 / 26 forces one table (measurements; 26 is never chosen by size); default by batch size
+    // ECGPU_FB_WINDOW = 8 / 16 / 20 / 24 / 26 pins one table width (measurements, small-memory processes);
+    // ECGPU_FB_MAX_WINDOW caps what the size rule may pick (default 26: 21.5 GB per 256-bit curve)
     static const int forced = [] { const char* e = getenv("ECGPU_FB_WINDOW"); return e ? atoi(e) : 0; }();
-    const int wb = forced ? forced : (n >= ((size_t)1 << 23) ? 24 : n >= ((size_t)1 << 21) ? 20 : n >= ((size_t)1 << 18) ? 16 : 8);
+    static const int cap = [] { const char* e = getenv("ECGPU_FB_MAX_WINDOW"); const int v = e ? atoi(e) : 26; return v < 8 ? 8 : v; }();
+    // (P-384 stops at 24 bits: its 26-bit table would be 48 GB and measured 45.2 ms against 46.4 ms per 2^24 results)
+    int wb = (n >= ((size_t)1 << 24) && C::NW <= 8) ? 26 : n >= ((size_t)1 << 23) ? 24 : n >= ((size_t)1 << 21) ? 20 : n >= ((size_t)1 << 18) ? 16 : 8;
+    if (wb > cap) wb = cap >= 26 ? 26 : cap >= 24 ? 24 : cap >= 20 ? 20 : cap >= 16 ? 16 : 8;
+    if (forced) wb = forced;
     if (wb == 26) return mul_gen_wide<26>(c, &c->fb26_table[C::ID], sc, out, out_fmt, out_inf, n);
     if (wb == 24) return mul_gen_wide<24>(c, &c->fb24_table[C::ID], sc, out, out_fmt, out_inf, n);
     if (wb == 20) return mul_gen_wide<20>(c, &c->fb20_table[C::ID], sc, out, out_fmt, out_inf, n);

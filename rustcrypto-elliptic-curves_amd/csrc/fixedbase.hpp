@@ -24,8 +24,9 @@ template <class C> constexpr int nwin() { return C::NB + 1; }            // one 
 //   WB = 16: 17 x 2^15 entries (36 MB per 256-bit curve, served from the Infinity Cache)      - batches >= 2^18
 //   WB = 20: 13 x 2^19 entries (436 MB per 256-bit curve, 1 GB for p384, HBM-resident gathers) - batches >= 2^21
 //   WB = 24: 11 x 2^23 entries (5.9 GB per 256-bit curve, 13.7 GB for p384; built in ~30 ms)  - batches >= 2^23
-//   WB = 26: 10 x 2^25 entries (21.5 GB per 256-bit curve; built in ~1.3 s)                     - ECGPU_FB_WINDOW=26 only
-//   (p256, 2^24 results: 16.1 / 14.2 / 13.1 ms with WB = 20 / 24 / 26 - every addition a window saves is 11 of ~140
+//   WB = 26: 10 x 2^25 entries (21.5 GB per 256-bit curve; built in ~85 ms)                   - batches >= 2^24, not p384
+//   (ECGPU_FB_MAX_WINDOW caps the width a context will build, ECGPU_FB_WINDOW pins it)
+//   (p256, 2^24 results: 16.1 / 14.2 / 13.3 ms with WB = 20 / 24 / 26 - every addition a window saves is 11 of ~140
 //   multiplications, and the gathers from a table no cache holds stay hidden behind them)
 // When WB divides the scalar width the signed recoding can carry out of the top window (one extra window that only
 // ever sees digit 1); otherwise the top window has spare bits and absorbs the carry.
@@ -123,10 +124,12 @@ __global__ void __launch_bounds__(256) table_from_bytes_kernel(const u32* xy, Af
   }
 }
 // scalars d * 2^(WB j) for j < nwin_wide, d = 1..2^(WB-1) (canonical big-endian bytes), reduced mod n
+// (entries first .. first + count of the table: the wide tables are built in chunks so that the scratch stays small)
 template <class C, int WB>
-__global__ void __launch_bounds__(256) table_scalars_kernel(u32* out, size_t total) {
+__global__ void __launch_bounds__(256) table_scalars_kernel(u32* out, size_t first, size_t count) {
   constexpr int NW = C::NW;
-  ECGPU_GRID_STRIDE(e, total) {
+  ECGPU_GRID_STRIDE(idx, count) {
+    const size_t e = first + idx;
     const int j = (int)(e / wide_entries<WB>());
     u32 d = (u32)(e % wide_entries<WB>()) + 1;
     // a carry window only ever sees digit 1 (k <= n/2 after the sign fold): its other entries are never read
@@ -168,7 +171,7 @@ __global__ void __launch_bounds__(256) table_scalars_kernel(u32* out, size_t tot
     } else {
       reduce_once<NW>(k, ord);
     }
-    words_store_be<NW>(out + e * NW, k);
+    words_store_be<NW>(out + idx * NW, k);
   }
 }
 

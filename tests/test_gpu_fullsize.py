@@ -151,12 +151,13 @@ def test_msm_full_sizes_structured(cname, cid, n, first):
     ctx.close()
 
 
-@pytest.mark.parametrize("cname,cid", [("k256", 0), ("p256", 1), ("p384", 2)])
-def test_fixed_base_24_bit_tables(cname, cid):
-    """mul_by_generator at 2^23 + 4 097 results: the size class that takes the 24-bit-window generator table (5.9 GB;
-    13.7 GB and a carry window for P-384), against the C oracle on the head, the tail and a strided sample, with a zero
-    scalar, n - 1, a scalar >= n and a scalar just above n / 2 (the sign fold) planted; and against the narrower tables
-    on a prefix (the same scalars through the 20-bit and 16-bit size classes must give the same bytes)."""
+@pytest.mark.parametrize("cname,cid,n", [("k256", 0, (1 << 23) + 4097), ("p256", 1, (1 << 24) + 5), ("p384", 2, (1 << 23) + 4097)])
+def test_fixed_base_wide_tables(cname, cid, n):
+    """mul_by_generator at the size classes that take the 24-bit-window generator table (2^23 + 4 097 results: 5.9 GB;
+    13.7 GB and a carry window for P-384) and the 26-bit one (2^24 + 5 results: 21.5 GB), against the C oracle on the head,
+    the tail and a strided sample, with a zero scalar, n - 1, a scalar >= n and a scalar just above n / 2 (the sign fold)
+    planted; and against the narrower tables on prefixes (the same scalars through the smaller size classes must give the
+    same bytes)."""
     import torch
     import ecgpu
     c = {0: synth.M.K256, 1: synth.M.P256, 2: synth.M.P384}[cid]
@@ -164,7 +165,6 @@ def test_fixed_base_24_bit_tables(cname, cid):
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     cv = ctx.curve(cname)
     nb = cv.nb
-    n = (1 << 23) + 4097
     d_s = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
     cv.synth_scalars_device(d_s, n, synth.SEED, 77)
     ctx.synchronize()
@@ -177,6 +177,7 @@ def test_fixed_base_24_bit_tables(cname, cid):
     d_s[n - 3] = row(c.n // 2 + 1)
     d_s[n - 2] = row(c.n // 2)
     d_s[n - 1] = row((1 << 24) - 1)                 # one full window of ones: a carry into the next window
+    d_s[n - 4] = row((1 << 52) - (1 << 25))         # the same for the 26-bit windows
     torch.cuda.synchronize()
     d_o = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
     d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
@@ -187,7 +188,7 @@ def test_fixed_base_24_bit_tables(cname, cid):
     want = CO.lincomb_batch(cid, np.ascontiguousarray(s[idx]), None, threads=THREADS)
     got = np.concatenate([d_o.cpu().numpy()[idx], d_i.cpu().numpy()[idx, None]], axis=1)
     assert bytes(got) == bytes(want)
-    for m in (1 << 21, 1 << 18):                    # the 20-bit and the 16-bit table on prefixes
+    for m in ((1 << 23, 1 << 21, 1 << 18) if n > (1 << 24) else (1 << 21, 1 << 18)):      # the narrower tables on prefixes
         d_o2 = torch.empty((m, 2 * nb), dtype=torch.uint8, device="cuda")
         cv.mul_device(d_s[:m], None, d_o2, m)
         ctx.synchronize()
