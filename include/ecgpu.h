@@ -228,10 +228,12 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* prehash, 
 /* sig_rs[i] = (r, s) with R = k G, r = x(R) mod n, s = k^-1 (z + r d) mod n; recovery_id[i] (optional) =
  * y_is_odd(R) | x_is_reduced << 1; ok[i] = 0 (and a zero signature) when d or k is outside [1, n-1]
  * or r = 0 or s = 0, where the reference returns Err.
- * k G runs on the reference's mul_by_generator schedule with its constant-time table scans (see
- * ECGPU_EXACT_REFERENCE) because the nonce is secret; ECGPU_PUBLIC_SCALARS in `flags` opts into the throughput
- * fixed-base schedule.  The signatures are identical either way.  Staged host copies of d and k are cleared before
- * the call returns. */
+ * The nonce is secret, so k G runs constant-time: by default on a fixed-base kernel that reads every entry of its
+ * 5-bit-window table and keeps the digit's one by masks, with the reference's complete addition formulas (3-4x the
+ * speed of the reference schedule on P-256 / P-384, whose mul_by_generator is the generic variable-base
+ * multiplication); ECGPU_EXACT_REFERENCE in `flags` selects the reference's own mul_by_generator schedule (constant-time
+ * as well), ECGPU_PUBLIC_SCALARS the digit-indexed throughput schedule.  The signatures are identical in all three.
+ * Staged host copies of d and k are cleared before the call returns. */
 int ecgpu_ecdsa_sign_batch(ecgpu_ctx* ctx, int curve, const uint8_t* secret_d, const uint8_t* nonce_k,
                            const uint8_t* prehash, uint8_t* sig_rs, uint8_t* recovery_id, uint8_t* ok,
                            size_t n, int mem, unsigned flags);

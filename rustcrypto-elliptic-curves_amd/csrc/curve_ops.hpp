@@ -146,6 +146,15 @@ struct CurveOps {
     HIPCHK(c, hipGetLastError());
     return 1;
   }
+  // k G for secret scalars: constant-time fixed-base kernel (fixedbase.hpp), one inversion per 8 results
+  static int mul_gen_ct(ecgpu_ctx* c, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
+    int rc = ensure_fb_wide_table<fb::CT_WB>(c, &c->fbct_table[C::ID]);
+    if (rc) return rc;
+    hipLaunchKernelGGL((fb::mul_ct_kernel<C, 8, 2>), dim3(ecgpu_grid_for(c, n, 2)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)c->fbct_table[C::ID], out, out_fmt,
+                       out_inf, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   // curve-specific throughput kernels hook in here (specialised in ops_*.hip); returns 1 if it launched
   static int lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt,
                           uint8_t* out_inf, size_t n);
@@ -320,10 +329,13 @@ struct CurveOps {
     if (rc) return rc;
     u32* r_xy = (u32*)c->ecdsa_ws;
     uint8_t* r_inf = (uint8_t*)c->ecdsa_ws + sz_p;
-    // The nonce is secret: k G runs on the reference's mul_by_generator schedule (complete formulas, constant-time
-    // table scans, no digit-dependent branch or address) unless the caller declares the scalars public.
-    if ((rc = lincomb(c, k, nullptr, FMT_AFFINE, 1, r_xy, FMT_AFFINE, r_inf, n, (flags & ECGPU_PUBLIC_SCALARS) ? 0u : (unsigned)ECGPU_EXACT_REFERENCE)))
-      return rc;
+    // The nonce is secret: k G runs on the constant-time fixed-base kernel (complete formulas, every table entry read,
+    // no digit-dependent branch or address) - or, with ECGPU_EXACT_REFERENCE, on the reference's own mul_by_generator
+    // schedule, which is constant-time as well - unless the caller declares the scalars public.
+    if (flags & ECGPU_PUBLIC_SCALARS) rc = lincomb(c, k, nullptr, FMT_AFFINE, 1, r_xy, FMT_AFFINE, r_inf, n, 0u);
+    else if (flags & ECGPU_EXACT_REFERENCE) rc = lincomb(c, k, nullptr, FMT_AFFINE, 1, r_xy, FMT_AFFINE, r_inf, n, (unsigned)ECGPU_EXACT_REFERENCE);
+    else rc = mul_gen_ct(c, k, r_xy, FMT_AFFINE, r_inf, n);
+    if (rc) return rc;
     hipLaunchKernelGGL((ecdsa::sign_finish_kernel<C, 16>), dim3(ecgpu_grid_for(c, (n + 15) / 16, 4)), dim3(256), 0, c->stream, d, k, z,
                        (const u32*)r_xy, (const uint8_t*)r_inf, sig, recid, ok, n, flags);
     HIPCHK(c, hipGetLastError());

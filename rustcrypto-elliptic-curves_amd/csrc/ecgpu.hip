@@ -209,6 +209,7 @@ void ecgpu_destroy(ecgpu_ctx* c) {
   for (int i = 0; i < 3; i++) if (c->fb16_table[i]) (void)hipFree(c->fb16_table[i]);
   for (int i = 0; i < 3; i++) if (c->fb20_table[i]) (void)hipFree(c->fb20_table[i]);
   for (int i = 0; i < 3; i++) if (c->fb24_table[i]) (void)hipFree(c->fb24_table[i]);
+  for (int i = 0; i < 3; i++) if (c->fbct_table[i]) (void)hipFree(c->fbct_table[i]);
   for (int i = 0; i < 3; i++) if (c->fb26_table[i]) (void)hipFree(c->fb26_table[i]);
   if (c->msm_ws) (void)hipFree(c->msm_ws);
   if (c->tab_ws) (void)hipFree(c->tab_ws);

@@ -32,6 +32,7 @@ struct ecgpu_ctx {
   void* fb_table[3] = {nullptr, nullptr, nullptr};
   void* fb16_table[3] = {nullptr, nullptr, nullptr};   // 16-bit-window variant for large batches
   void* fb20_table[3] = {nullptr, nullptr, nullptr};   // 20-bit-window variant for very large batches
+  void* fbct_table[3] = {nullptr, nullptr, nullptr};   // 5-bit windows, read in full by the constant-time kernel (signing)
   void* fb24_table[3] = {nullptr, nullptr, nullptr};   // 24-bit windows (5.9 GB for a 256-bit curve): batches of 2^23 and more
   void* fb26_table[3] = {nullptr, nullptr, nullptr};   // 26-bit windows (21 GB): on request only (ECGPU_FB_WINDOW=26)
   // per-lane table workspace of the k256 variable-base kernel (grow-only)

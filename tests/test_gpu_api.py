@@ -180,8 +180,11 @@ def test_point_eq_and_checked_scalars(cn, cid):
 
 @pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1), ("p384", 2)])
 def test_signing_schedules_agree_and_ecdh(cn, cid):
-    """Signing defaults to the constant-time reference schedule for k G; ECGPU_PUBLIC_SCALARS opts into the throughput
-    schedule.  Same signatures.  ECDH (a secret-scalar multiplication) goes through the reference schedule too."""
+    """Signing defaults to the constant-time fixed-base kernel for k G (every table entry read, complete additions);
+    ECGPU_EXACT_REFERENCE selects the reference's own constant-time schedule, ECGPU_PUBLIC_SCALARS the throughput
+    schedule.  Same signatures from all three, edge nonces included (1, 2, n - 1, n - 2, single-window digits 16 and 17,
+    runs of ones that carry through every window, and 0 / n, which must come back not ok).  ECDH (a secret-scalar
+    multiplication) goes through the reference schedule."""
     import ecgpu
     ctx = ecgpu.Context(0)
     cv = ctx.curve(cn)
@@ -189,12 +192,26 @@ def test_signing_schedules_agree_and_ecdh(cn, cid):
     d = CO.synth_scalars(cid, n, synth.SEED, 21)
     k = CO.synth_scalars(cid, n, synth.SEED + 1, 21)
     z = CO.synth_scalars(cid, n, synth.SEED + 2, 21)
+    c = synth.M.CURVES[cn]
+    nb = c.nbytes
+    edge = [1, 2, 15, 16, 17, 31, 32, 33, c.n - 1, c.n - 2, c.n - 16, (1 << (8 * nb - 3)) - 1, int("f" * (2 * nb - 2), 16), (1 << 250) + (1 << 5) * 16,
+            c.n // 2, c.n // 2 + 1, 0, c.n]
+    for i, v in enumerate(edge):
+        k[1000 + i] = np.frombuffer(int(v).to_bytes(nb, "big"), dtype=np.uint8)
+    bad = [1000 + len(edge) - 2, 1000 + len(edge) - 1]               # k = 0 and k = n
     fl = cv.default_ecdsa_flags()
     sig_ct, rec_ct, ok_ct = cv.ecdsa_sign(d, k, z, flags=fl)
     sig_pub, rec_pub, ok_pub = cv.ecdsa_sign(d, k, z, flags=fl | ecgpu.PUBLIC_SCALARS)
-    assert ok_ct.all() and bytes(sig_ct) == bytes(sig_pub) and bytes(rec_ct) == bytes(rec_pub) and bytes(ok_ct) == bytes(ok_pub)
+    sig_ref, rec_ref, ok_ref = cv.ecdsa_sign(d, k, z, flags=fl | ecgpu.EXACT_REFERENCE)
+    assert not ok_ct[bad].any() and ok_ct.sum() == n - len(bad)
+    assert bytes(sig_ct) == bytes(sig_pub) and bytes(rec_ct) == bytes(rec_pub) and bytes(ok_ct) == bytes(ok_pub)
+    assert bytes(sig_ct) == bytes(sig_ref) and bytes(rec_ct) == bytes(rec_ref) and bytes(ok_ct) == bytes(ok_ref)
     s2, r2, _ = CO.ecdsa_sign_batch(cid, d[:200], k[:200], z[:200], low_s=(cid == 0))
     assert bytes(sig_ct[:200]) == bytes(s2) and bytes(rec_ct[:200]) == bytes(r2)
+    lo, hi = 1000, 1000 + len(edge) - 2              # the valid edge nonces against the oracle
+    s3, r3, _ = CO.ecdsa_sign_batch(cid, d[lo:hi], k[lo:hi], z[lo:hi], low_s=(cid == 0))
+    assert bytes(sig_ct[lo:hi]) == bytes(s3) and bytes(rec_ct[lo:hi]) == bytes(r3)
+    k[bad] = k[0]                                    # ECDH below wants valid scalars
     q, _ = cv.mul_by_generator(d)
     shared = cv.diffie_hellman(k, q)                 # k (dG)
     q2, _ = cv.mul_by_generator(k)

@@ -20,7 +20,7 @@ from oracle import ecmodel as M
 
 n = 1 << 16
 ctx = ecgpu.Context(0)
-for cname in ("k256", "p256"):
+for cname in ("k256", "p256", "p384"):
     c = M.CURVES[cname]
     cv = ctx.curve(cname)
     nb = cv.nb
@@ -42,5 +42,16 @@ for cname in ("k256", "p256"):
             ctx.synchronize()
             cv.mul_device(d_s, d_p, d_o, n, out_format=ecgpu.PROJECTIVE, flags=flags)         # variable base
             ctx.synchronize()
+    # signing: the nonce k takes the three sets (default flags: the constant-time fixed-base kernel fb::mul_ct_kernel)
+    d_d = torch.from_numpy(np.ascontiguousarray(sets[2])).cuda()
+    d_z = torch.from_numpy(np.ascontiguousarray(sets[2][::-1])).cuda()
+    d_sig = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+    d_rec = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    d_ok = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    for s in sets:
+        d_k = torch.from_numpy(np.ascontiguousarray(s)).cuda()
+        torch.cuda.synchronize()
+        cv.ecdsa_sign_device(d_d, d_k, d_z, d_sig, d_rec, d_ok, n)
+        ctx.synchronize()
 ctx.close()
 print("done")

@@ -18,7 +18,7 @@ by_kernel = defaultdict(list)
 for (d, k), c in sorted(per.items()):
     by_kernel[k].append((d, c))
 for k, lst in by_kernel.items():
-    if not any(t in k for t in ("mul_gen_ref", "lincomb_ref", "mul_kernel", "mul_fast", "mul_wide")):
+    if not any(t in k for t in ("mul_gen_ref", "lincomb_ref", "mul_kernel", "mul_fast", "mul_wide", "mul_ct_kernel", "sign_finish")):
         continue
     names = sorted(lst[0][1])
     print(k)
