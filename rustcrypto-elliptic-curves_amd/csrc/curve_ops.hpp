@@ -150,8 +150,9 @@ struct CurveOps {
   static int mul_gen_ct(ecgpu_ctx* c, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
     int rc = ensure_fb_wide_table<fb::CT_WB>(c, &c->fbct_table[C::ID]);
     if (rc) return rc;
-    hipLaunchKernelGGL((fb::mul_ct_kernel<C, 8, 2>), dim3(ecgpu_grid_for(c, n, 2)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)c->fbct_table[C::ID], out, out_fmt,
-                       out_inf, n);
+    constexpr int WAVES = C::NW > 8 ? 2 : (C::ID == 0 ? 3 : 4);       // what the complete addition's live set allows: 230 / 146 / 127 VGPRs
+    hipLaunchKernelGGL((fb::mul_ct_kernel<C, 8, WAVES>), dim3(ecgpu_grid_for(c, n, WAVES)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)c->fbct_table[C::ID], out,
+                       out_fmt, out_inf, n);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
