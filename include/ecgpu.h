@@ -95,8 +95,14 @@ enum {
   ECGPU_ECDSA_LOW_S = 2u,
   /* ecgpu_ecdsa_sign_batch only: the nonces are not secret (test vectors, benchmarks, deterministic replays of public
    * data), so k G may run on the throughput fixed-base schedule (digit-indexed table reads, ~4x faster).  Without it
-   * signing uses the constant-time reference schedule for k G. */
-  ECGPU_PUBLIC_SCALARS = 4u
+   * signing runs k G constant-time (see ecgpu_ecdsa_sign_batch). */
+  ECGPU_PUBLIC_SCALARS = 4u,
+  /* ecgpu_mul_batch / ecgpu_lincomb_batch: the scalars are secret and only the group element is wanted (key generation:
+   * PublicKey::from_secret_scalar is d G).  With points == NULL the multiplication runs on the constant-time fixed-base
+   * kernel signing uses (every table entry read, complete additions; the result is the same point, not the reference's
+   * (X, Y, Z)); with a variable base point the flag selects the reference schedule, the constant-time one there is.
+   * Staged host copies of the scalars are cleared as with ECGPU_EXACT_REFERENCE. */
+  ECGPU_SECRET_SCALARS = 8u
 };
 
 /* ---- context ------------------------------------------------------------------------------

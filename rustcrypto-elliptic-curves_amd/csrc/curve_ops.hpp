@@ -161,6 +161,10 @@ struct CurveOps {
                           uint8_t* out_inf, size_t n);
   static int lincomb(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt, uint8_t* out_inf,
                      size_t n, unsigned flags) {
+    if ((flags & ECGPU_SECRET_SCALARS) && !(flags & ECGPU_EXACT_REFERENCE)) {
+      if (!pts && terms == 1) return mul_gen_ct(c, sc, out, out_fmt, out_inf, n);
+      flags |= ECGPU_EXACT_REFERENCE;              // variable base: the reference schedule is the constant-time one
+    }
     if (!(flags & ECGPU_EXACT_REFERENCE)) {
       int rc = lincomb_fast(c, sc, pts, pt_fmt, terms, out, out_fmt, out_inf, n);
       if (rc < 0) return rc;

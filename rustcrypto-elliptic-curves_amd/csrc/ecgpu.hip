@@ -363,7 +363,7 @@ static int lincomb_impl(ecgpu_ctx* c, int curve, const uint8_t* scalars, const u
   ENTER(c, curve);
   const size_t pin = (pt_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb, pout = (out_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb;
   // the reference schedule is the one meant for secret scalars: their staged copies do not outlive the call
-  const bool secret = (flags & ECGPU_EXACT_REFERENCE) != 0;
+  const bool secret = (flags & (ECGPU_EXACT_REFERENCE | ECGPU_SECRET_SCALARS)) != 0;
   if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
     const PipeArg args[5] = {{scalars, nullptr, terms * nb}, {points, nullptr, points ? terms * pin : 0}, {nullptr, out, pout},
                              {nullptr, out_fmt == ECGPU_PT_AFFINE ? out_inf : nullptr, 1}, {nullptr, scalar_ok, 1}};

@@ -28,6 +28,7 @@ AFFINE, PROJECTIVE = 0, 1
 EXACT_REFERENCE = 1
 ECDSA_LOW_S = 2
 PUBLIC_SCALARS = 4
+SECRET_SCALARS = 8
 K256, P256, P384 = 0, 1, 2
 CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384}
 FIELD_BYTES = {K256: 32, P256: 32, P384: 48}

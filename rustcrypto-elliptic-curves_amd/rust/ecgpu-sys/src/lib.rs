@@ -38,6 +38,8 @@ pub const ECGPU_EXACT_REFERENCE: c_uint = 1;
 pub const ECGPU_ECDSA_LOW_S: c_uint = 2;
 /// signing only: the nonces are public, k G may use the throughput fixed-base schedule
 pub const ECGPU_PUBLIC_SCALARS: c_uint = 4;
+/// secret scalars, group element only: constant-time fixed base for k G (key generation), the reference schedule for a variable base
+pub const ECGPU_SECRET_SCALARS: c_uint = 8;
 
 #[link(name = "ecgpu")]
 extern "C" {

@@ -222,6 +222,34 @@ def test_signing_schedules_agree_and_ecdh(cn, cid):
     ctx.close()
 
 
+@pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1), ("p384", 2)])
+def test_secret_scalars_flag(cn, cid):
+    """ECGPU_SECRET_SCALARS: key generation d G on the constant-time fixed-base kernel, a variable base on the reference
+    schedule - the same affine bytes as the throughput schedules, identity results (d = 0, d = n) flagged, projective
+    output normalised to Z = 1 (identity (0, 1, 0))."""
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cn)
+    c = synth.M.CURVES[cn]
+    nb = c.nbytes
+    n = 5000
+    d = CO.synth_scalars(cid, n, synth.SEED, 91)
+    for i, v in enumerate([0, c.n, 1, 2, 16, 17, c.n - 1, c.n + 5, c.n // 2, c.n // 2 + 1, (1 << (8 * nb)) - 1]):
+        d[40 + i] = np.frombuffer(int(v).to_bytes(nb, "big"), dtype=np.uint8)
+    pub, inf = cv.mul_by_generator(d)
+    pub_ct, inf_ct = cv.mul_by_generator(d, flags=ecgpu.SECRET_SCALARS)
+    assert bytes(pub_ct) == bytes(pub) and bytes(inf_ct) == bytes(inf) and inf[40] == 1 and inf[41] == 1 and inf.sum() == 2
+    proj = cv.mul_by_generator(d, out_format=ecgpu.PROJECTIVE, flags=ecgpu.SECRET_SCALARS)
+    proj = proj[0] if isinstance(proj, tuple) else proj
+    one = (1).to_bytes(nb, "big")
+    assert bytes(proj[7]) == bytes(pub[7]) + one and bytes(proj[40]) == bytes(nb) + one + bytes(nb)
+    p = CO.synth_points(cid, 300, synth.SEED, 92)
+    a, ai = cv.mul(d[:300], p)
+    b, bi = cv.mul(d[:300], p, flags=ecgpu.SECRET_SCALARS)
+    assert bytes(a) == bytes(b) and bytes(ai) == bytes(bi)
+    ctx.close()
+
+
 def test_plain_c_caller():
     """The boundary from C, without Python in the data path: examples/abi_example.c (generator multiples, complete
     addition, point equality, sign + verify) exits 0."""
