@@ -12,6 +12,7 @@
 // Device code only.
 #pragma once
 #include "jacobian.hpp"
+#include "fixedbase_ct.hpp"
 #include "kernels.hpp"
 
 namespace ecgpu {
@@ -231,6 +232,7 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
 // generic variable-base multiplication (256 doublings: primeorder/src/projective.rs:422-431, "TODO: precomputed
 // basepoint tables").  This kernel gives the same group element k G with no doubling and nothing that depends on k but
 // data:
+//   (the per-result body is mul_ct_one in fixedbase_ct.hpp, host + device, so that the host twin can trace its table reads)
 //   * signed 5-bit digits by branch-free recoding; table T[j][d-1] = d 2^(5j) G, d = 1..16 (52 x 16 entries for a
 //     256-bit curve: 53 KB, the wide-table builder with WB = 5);
 //   * EVERY entry of window j is read (the address depends on j and the entry number only - one broadcast load for the
@@ -240,11 +242,10 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
 //   * one inversion per BATCH results (Montgomery's trick on the homogeneous Z; a zero Z is masked to 1 and flagged).
 // 52 (77) complete additions instead of the reference schedule's 256 (384) doublings and 64 (96) additions.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int CT_WB = 5;
 template <class C, int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) mul_ct_kernel(const u32* scalars, const AffEntry<C>* table, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
-  constexpr int NW = C::NW, NWIN = nwin_wide<C, CT_WB>(), NENT = wide_entries<CT_WB>();
-  static_assert(!wide_carry_window<C, CT_WB>(), "the top window must have room for the last carry");
+  constexpr int NW = C::NW;
+  static_assert(ct_nwin<C>() == nwin_wide<C, CT_WB>() && CT_ENTRIES == wide_entries<CT_WB>(), "the table is the wide-table builder's with WB = 5");
   using Fe = typename C::Fe;
   using Pt = typename C::Pt;
   Pt res[BATCH];
@@ -262,40 +263,7 @@ __global__ void __launch_bounds__(256, WAVES) mul_ct_kernel(const u32* scalars, 
       C::order(ord);
       reduce_once<NW>(k, ord);
       Pt acc;
-      C::pt_identity(acc);
-      u32 carry = 0;
-#pragma unroll 1
-      for (int j = 0; j < NWIN; j++) {
-        const int wi = (CT_WB * j) >> 5, sh = (CT_WB * j) & 31;       // public: the window number
-        u32 w0 = 0, w1 = 0;
-#pragma unroll
-        for (int q = 0; q < NW; q++) { w0 = (wi == q) ? k[q] : w0; w1 = (wi + 1 == q) ? k[q] : w1; }
-        const u64 pair = ((u64)w1 << 32) | w0;
-        const u32 v = ((u32)(pair >> sh) & ((1u << CT_WB) - 1u)) + carry;            // 0 .. 32
-        carry = (j == NWIN - 1) ? 0u : ((v + (1u << (CT_WB - 1))) >> CT_WB);         // v >= 16 -> v - 32 and a carry; the top window keeps v
-        const int d = (int)v - (int)(carry << CT_WB);                                // -16 .. 16
-        const u32 sgn = (u32)(d >> 31), mag = ((u32)d ^ sgn) - sgn;                  // |d| without a branch
-        typename C::Af q;
-        C::fe_zero(q.x);
-        C::fe_zero(q.y);
-        const AffEntry<C>* row = table + (size_t)j * NENT;
-        // arithmetic masks, not selects: a select of a loaded value lets the compiler load only under the condition
-        // (it did: the VMEM instruction count followed the digits until this was an AND / OR)
-#pragma unroll 4
-        for (int e = 0; e < NENT; e++) {
-          const u32 mk = 0u - (((mag ^ (u32)(e + 1)) - 1u) >> 31);          // all ones iff mag == e + 1
-          const AffEntry<C> t = row[e];
-#pragma unroll
-          for (int w = 0; w < NW; w++) { q.x.v[w] |= t.x.v[w] & mk; q.y.v[w] |= t.y.v[w] & mk; }
-        }
-        Fe ny;
-        C::fe_neg(ny, q.y);
-        C::fe_select(q.y, sgn != 0, ny, q.y);
-        q.inf = (mag == 0) ? 1u : 0u;
-        Pt t;
-        C::pt_add_mixed(t, acc, q);
-        acc = t;
-      }
+      mul_ct_one<C>(acc, k, table);
       res[b] = acc;
       cnt = b + 1;
     }

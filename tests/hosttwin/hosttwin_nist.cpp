@@ -180,3 +180,29 @@ extern "C" int ht_h2c_map(int curve, const uint8_t* u, int count, uint8_t* out_x
   if (curve == 0) return h2c_map_host<CurveK256>(u, count, out_xy, out_inf, n);
   return curve == 1 ? h2c_map_host<CurveP256>(u, count, out_xy, out_inf, n) : h2c_map_host<CurveP384>(u, count, out_xy, out_inf, n);
 }
+
+// ---- constant-time fixed base (fixedbase_ct.hpp): k G from a table T[j][d-1] = d 2^(5j) G given as canonical x||y rows;
+//      out = X||Y||Z (the reference's homogeneous projective coordinates).  The trace hook records every table entry read.
+#include "fixedbase_ct.hpp"
+template <class C>
+static int mul_ct(const uint8_t* table_xy, const uint8_t* ks, uint8_t* out, int n) {
+  const int total = fb::ct_nwin<C>() * fb::CT_ENTRIES;
+  AffEntry<C>* tab = (AffEntry<C>*)malloc(sizeof(AffEntry<C>) * total);
+  for (int e = 0; e < total; e++) { load<C>(tab[e].x, table_xy + 2 * C::NB * e); load<C>(tab[e].y, table_xy + 2 * C::NB * e + C::NB); }
+  for (int i = 0; i < n; i++) {
+    u32 w[C::NW], k[C::NW], ord[C::NW];
+    memcpy(w, ks + C::NB * i, C::NB);
+    C::scalar_load(k, w);
+    C::order(ord);
+    reduce_once<C::NW>(k, ord);
+    typename C::Pt r;
+    fb::mul_ct_one<C>(r, k, tab);
+    store_pt<C>(out + 3 * C::NB * i, r);
+  }
+  free(tab);
+  return 0;
+}
+extern "C" int ht_mul_ct(int curve, const uint8_t* table_xy, const uint8_t* ks, uint8_t* out, int n) {
+  if (curve == 0) return mul_ct<CurveK256>(table_xy, ks, out, n);
+  return curve == 1 ? mul_ct<CurveP256>(table_xy, ks, out, n) : mul_ct<CurveP384>(table_xy, ks, out, n);
+}

@@ -173,3 +173,35 @@ def test_vb_two_term_lincomb_walk(cn, cid, lanes, n):
             assert got == bytes(2 * nb) and bytes(inf)[i] == 1, i
         else:
             assert got == M.i2b(c, want[0]) + M.i2b(c, want[1]) and bytes(inf)[i] == 0, i
+
+
+@pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1), ("p384", 2)])
+def test_constant_time_fixed_base_reads_the_whole_table(cn, cid):
+    """fb::mul_ct_one (the body of the signing kernel fb::mul_ct_kernel): k G for edge and random scalars against the
+    big-integer model, and the sequence of table entries read - every entry of every window, in order - is the same for
+    every scalar."""
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    nwin = (8 * nb + 4) // 5
+    G = (c.G[0], c.G[1])
+    rows = []
+    for j in range(nwin):
+        base = M.affine_mul(c, pow(2, 5 * j, c.n), G)
+        acc = None
+        for d in range(1, 17):
+            acc = M.affine_add(c, acc, base)
+            rows.append(M.i2b(c, acc[0]) + M.i2b(c, acc[1]))
+    table = b"".join(rows)
+    scalars = [0, 1, 2, 15, 16, 17, 31, 32, 33, c.n - 1, c.n - 2, c.n - 16, c.n - 17, c.n // 2, c.n // 2 + 1, int("f" * (2 * nb - 1), 16),
+               int("8" * (2 * nb), 16) % c.n, (1 << (8 * nb - 1)), c.n, c.n + 5] + [synth.scalar(c, 900 + i) for i in range(6)]
+    L = lib()
+    L.ht_mul_ct.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    traces = []
+    for k in scalars:
+        out = outbuf(3 * nb)
+        traces.append(_trace(lambda: L.ht_mul_ct(cid, buf(table), buf(int(k).to_bytes(nb, "big")), out, 1)))
+        X, Y, Z = (int.from_bytes(bytes(out)[nb * t:nb * (t + 1)], "big") for t in range(3))
+        want = M.affine_mul(c, k % c.n, G) if k % c.n else None
+        got = None if Z == 0 else (X * pow(Z, -1, c.p) % c.p, Y * pow(Z, -1, c.p) % c.p)
+        assert got == want, hex(k)
+    assert all(t == traces[0] for t in traces) and traces[0] == list(range(nwin * 16))
