@@ -353,8 +353,8 @@ def run_workload(env, name, log2n, steps, warmup, schedule, cpu):
     torch.cuda.synchronize()
     d_part = torch.empty((3 * nb,), dtype=torch.uint8, device=dev)
     d_all = torch.empty((max(world, 1), 3 * nb), dtype=torch.uint8, device=dev)
-    d_ones = torch.zeros((max(world, 1), nb), dtype=torch.uint8, device=dev)
-    d_ones[:, nb - 1] = 1
+    d_fold = torch.empty((max(world, 1), 3 * nb), dtype=torch.uint8, device=dev)       # scratch of the fold of the gathered points
+    d_fold_inf = torch.empty((1,), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
     def step():
@@ -370,7 +370,7 @@ def run_workload(env, name, log2n, steps, warmup, schedule, cpu):
                 parallel.allgather_into(d_all, d_part, backend, synchronize=ctx.synchronize)
                 if backend != "nccl":
                     torch.cuda.synchronize()
-                cv.msm_device(d_ones, d_all, world, d_o, point_format=ecgpu.PROJECTIVE)
+                parallel.fold_points_device(cv, d_all, world, d_fold, d_o, d_fold_inf)
         else:
             cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i, flags=(ecgpu.EXACT_REFERENCE if schedule == "ref" else 0))
 

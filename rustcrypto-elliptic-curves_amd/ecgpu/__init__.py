@@ -252,6 +252,18 @@ class Curve:
         self.ctx.check(self.ctx.lib.ecgpu_batch_normalize(self.ctx.handle, self.id, _ptr(p)[0], _ptr(out)[0], _ptr(inf)[0], len(p), HOST))
         return out, inf
 
+    def add_device(self, d_p_xyz, d_q_xyz, d_out_xyz, n: int):
+        """complete addition on device-resident projective points (torch tensors / device pointers)"""
+        for t, nm in ((d_p_xyz, "d_p_xyz"), (d_q_xyz, "d_q_xyz"), (d_out_xyz, "d_out_xyz")):
+            self._check_device(t, n * 3 * self.nb, nm)
+        self.ctx.check(self.ctx.lib.ecgpu_point_add_batch(self.ctx.handle, self.id, _ptr(d_p_xyz)[0], _ptr(d_q_xyz)[0], _ptr(d_out_xyz)[0], n, DEVICE))
+
+    def batch_normalize_device(self, d_p_xyz, d_out_xy, d_out_inf, n: int):
+        self._check_device(d_p_xyz, n * 3 * self.nb, "d_p_xyz")
+        self._check_device(d_out_xy, n * 2 * self.nb, "d_out_xy")
+        self._check_device(d_out_inf, n, "d_out_inf")
+        self.ctx.check(self.ctx.lib.ecgpu_batch_normalize(self.ctx.handle, self.id, _ptr(d_p_xyz)[0], _ptr(d_out_xy)[0], _ptr(d_out_inf)[0], n, DEVICE))
+
     def point_eq(self, p_xyz, q_xyz) -> np.ndarray:
         """ProjectivePoint == ProjectivePoint (ct_eq) per element -> uint8 flags"""
         p, q = _as_host(p_xyz, 3 * self.nb), _as_host(q_xyz, 3 * self.nb)

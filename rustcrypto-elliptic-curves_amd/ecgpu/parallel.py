@@ -56,6 +56,29 @@ def allgather_into(all_parts, part, backend: str, group=None, synchronize=None):
     return all_parts
 
 
+def fold_points_device(cv, d_points_xyz, count: int, d_scratch_xyz, d_out_xy, d_out_inf):
+    """Sum `count` device-resident projective points (the all-gathered partial sums of a split MSM) by a tree of complete
+    additions and normalise the result: ceil(log2 count) + 1 small launches, no scalar multiplication (an MSM with unit
+    scalars would spend a whole scalar multiplication's latency, ~1 ms, on it).
+
+    d_points_xyz, d_scratch_xyz: (>= count, 3*NB) uint8 device tensors (both are overwritten); d_out_xy (2*NB,), d_out_inf (1,)."""
+    # Only library calls touch the buffers (all on the context's stream): a tree over the even part of every level, the
+    # odd row of a level is left where it is - later levels write below it - and added at the end.
+    cur, other = d_points_xyz, d_scratch_xyz
+    leftovers = []
+    while count > 1:
+        half = count // 2
+        if count & 1:
+            leftovers.append(cur[count - 1:count])
+        cv.add_device(cur[:half], cur[half:2 * half], other[:half], half)
+        count = half
+        cur, other = other, cur
+    for row in leftovers:
+        cv.add_device(cur[:1], row, other[:1], 1)
+        cur, other = other, cur
+    cv.batch_normalize_device(cur[:1], d_out_xy, d_out_inf, 1)
+
+
 def msm_sharded(local_msm: Callable[[int, int], np.ndarray], add_points: Callable[[np.ndarray, np.ndarray], np.ndarray],
                 n: int, group=None) -> np.ndarray:
     """sum_i k_i P_i over n terms split across the ranks of `group`.

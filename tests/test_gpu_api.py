@@ -250,6 +250,46 @@ def test_secret_scalars_flag(cn, cid):
     ctx.close()
 
 
+@pytest.mark.parametrize("cn,cid", [("k256", 0), ("p384", 2)])
+def test_fold_points_device(cn, cid):
+    """parallel.fold_points_device: the all-gathered partial sums of a split MSM (one projective point per rank) are summed
+    on the device by a tree of complete additions - any count, an identity among them, opposite points."""
+    import torch
+    import ecgpu
+    from ecgpu import parallel
+    c = synth.M.CURVES[cn]
+    nb = c.nbytes
+    ctx = ecgpu.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    cv = ctx.curve(cn)
+    rng = np.random.default_rng(5)
+    pts = [synth.point(c, 300 + i, seed=44) for i in range(9)]
+    pts[3] = None
+    pts[6] = synth.M.affine_neg(c, pts[5])
+    for count in (1, 2, 3, 5, 8, 9):
+        rows = []
+        for p in pts[:count]:
+            if p is None:
+                rows.append(synth.M.proj_bytes(c, synth.M.IDENTITY))
+            else:
+                z = int(rng.integers(2, 1 << 62))
+                rows.append(synth.M.proj_bytes(c, (p[0] * z % c.p, p[1] * z % c.p, z)))
+        d_all = torch.from_numpy(np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(count, 3 * nb).copy()).cuda()
+        d_scr = torch.empty_like(d_all)
+        d_out = torch.empty((2 * nb,), dtype=torch.uint8, device="cuda")
+        d_inf = torch.empty((1,), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        parallel.fold_points_device(cv, d_all, count, d_scr, d_out, d_inf)
+        ctx.synchronize()
+        want = None
+        for p in pts[:count]:
+            want = synth.M.affine_add(c, want, p)
+        got = bytes(d_out.cpu().numpy())
+        assert got == (bytes(2 * nb) if want is None else synth.M.i2b(c, want[0]) + synth.M.i2b(c, want[1])), count
+        assert int(d_inf.cpu()[0]) == (1 if want is None else 0)
+    ctx.close()
+
+
 def test_plain_c_caller():
     """The boundary from C, without Python in the data path: examples/abi_example.c (generator multiples, complete
     addition, point equality, sign + verify) exits 0."""
