@@ -85,6 +85,43 @@ ECGPU_HD void xyzz_add_mixed(Xyzz<C>& p, const typename C::Fe& x2, const typenam
   C::fe_sub(q, q, p.x); C::fe_mul(q, r, q);                  // R (Q - X3)
   C::fe_sub(p.y, q, t);
 }
+// p += q, both in XYZZ coordinates (add-2008-s: 12M + 2S; a bucket left in pieces by the equal-run bucket sums is the sum of
+// its pieces).  Exceptional cases by control flow: either operand at infinity, the same point (doubling, through the
+// Jacobian doubling), opposite points (infinity).
+template <class C>
+ECGPU_HD void jacobian_to_xyzz(Xyzz<C>& r, const Jac<C>& p);
+template <class C>
+ECGPU_HD void xyzz_add(Xyzz<C>& p, const Xyzz<C>& q) {
+  using Fe = typename C::Fe;
+  if (C::fe_is_zero_fast(q.zz)) return;
+  if (C::fe_is_zero_fast(p.zz)) { p = q; return; }
+  Fe u1, u2, s1, s2, pp, t;
+  C::fe_mul(u1, p.x, q.zz); C::fe_mul(u2, q.x, p.zz);
+  C::fe_mul(s1, p.y, q.zzz); C::fe_mul(s2, q.y, p.zzz);
+  C::fe_sub(u2, u2, u1);                                     // P = U2 - U1
+  C::fe_sub(s2, s2, s1);                                     // R = S2 - S1
+  if (__builtin_expect(C::fe_is_zero_fast(u2), 0)) {
+    if (C::fe_is_zero(s2)) {                                 // the same point: 2 p through (X ZZ, Y ZZZ, ZZ)
+      Jac<C> d;
+      C::fe_mul(d.x, p.x, p.zz); C::fe_mul(d.y, p.y, p.zzz); d.z = p.zz;
+      pt_dbl<C>(d);
+      jacobian_to_xyzz<C>(p, d);
+    } else {
+      xyzz_set_infinity<C>(p);
+    }
+    return;
+  }
+  C::fe_sqr(pp, u2);                                         // PP
+  C::fe_mul(u1, u1, pp);                                     // Q = U1 PP
+  C::fe_mul(t, p.zz, q.zz); C::fe_mul(p.zz, t, pp);          // ZZ3 = ZZ1 ZZ2 PP
+  C::fe_mul(pp, pp, u2);                                     // PPP
+  C::fe_mul(t, p.zzz, q.zzz); C::fe_mul(p.zzz, t, pp);       // ZZZ3 = ZZZ1 ZZZ2 PPP
+  C::fe_sqr(t, s2);
+  C::fe_sub(t, t, pp); C::fe_sub(t, t, u1); C::fe_sub(p.x, t, u1);     // X3 = R^2 - PPP - 2Q
+  C::fe_mul(s1, s1, pp);                                     // S1 PPP
+  C::fe_sub(u1, u1, p.x); C::fe_mul(u1, s2, u1);             // R (Q - X3)
+  C::fe_sub(p.y, u1, s1);
+}
 // (X, Y, Z) -> (X, Y, Z^2, Z^3): the same point, x = X / Z^2, y = Y / Z^3
 template <class C>
 ECGPU_HD void jacobian_to_xyzz(Xyzz<C>& r, const Jac<C>& p) {

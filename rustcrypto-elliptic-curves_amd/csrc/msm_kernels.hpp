@@ -692,16 +692,13 @@ __global__ void __launch_bounds__(256) span_combine_kernel(const u32* offsets, i
       for (u32 q = 0; q < k; q++) chunks[base + q] = HeavyChunk{b, q};
       continue;
     }
-    Jac<C> acc, pc;
-    load_piece<C>(acc, head, tail, t0, 0);
+    Xyzz<C> acc = tail[t0];                      // piece 0; pieces p >= 1 are head[t0 + p]
 #pragma unroll 1
     for (u32 p = 1; p < np; p++) {
-      load_piece<C>(pc, head, tail, t0, p);
-      pt_add<C>(acc, acc, pc);
+      const Xyzz<C> pc = head[t0 + p];
+      xyzz_add<C>(acc, pc);
     }
-    Xyzz<C> r;
-    jacobian_to_xyzz<C>(r, acc);
-    store_xyzz<C>(&bucketsX[b], r);
+    store_xyzz<C>(&bucketsX[b], acc);
   }
 }
 

@@ -136,6 +136,14 @@ static int xyzz_op(const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
     msm::xyzz_add_mixed<C>(a, x, y);
     Jac<C> r;
     msm::xyzz_to_jacobian<C>(r, a);
+    if ((i & 3) == 2) {                           // every fourth entry: the same sum by the general XYZZ addition instead
+      load<C>(a.x, p + 4 * C::NB * i); load<C>(a.y, p + 4 * C::NB * i + C::NB); load<C>(a.zz, p + 4 * C::NB * i + 2 * C::NB); load<C>(a.zzz, p + 4 * C::NB * i + 3 * C::NB);
+      // the addend in XYZZ form with a denominator that is not one: (x u^2, y u^3, u^2, u^3) for u = x + 1
+      typename C::Fe one, u, u2, u3; C::fe_one(one); C::fe_add(u, x, one); C::fe_sqr(u2, u); C::fe_mul(u3, u2, u);
+      msm::Xyzz<C> qq; C::fe_mul(qq.x, x, u2); C::fe_mul(qq.y, y, u3); qq.zz = u2; qq.zzz = u3;
+      msm::xyzz_add<C>(a, qq);
+      msm::xyzz_to_jacobian<C>(r, a);
+    }
     if (i & 1) {                                  // odd entries also go through the way back, as the folded bucket pieces do
       msm::Xyzz<C> b;
       msm::jacobian_to_xyzz<C>(b, r);

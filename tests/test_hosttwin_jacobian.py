@@ -61,8 +61,9 @@ def test_jacobian_ops(cn, cid):
 
 @pytest.mark.parametrize("cn,cid", CURVES)
 def test_xyzz_bucket_accumulator(cn, cid):
-    """XYZZ mixed addition of the MSM bucket sums (msm.hpp, all curves) and its conversion to Jacobian, with the
-    exceptional cases: accumulator at infinity, the same point (doubling), opposite points."""
+    """XYZZ mixed addition of the MSM bucket sums (msm.hpp, all curves), the general XYZZ addition that folds bucket pieces
+    (every fourth entry) and the conversions to and from Jacobian, with the exceptional cases: accumulator at infinity,
+    the same point (doubling), opposite points."""
     c = M.CURVES[cn]
     p, nb = c.p, c.nbytes
     rng = random.Random(72)
@@ -78,6 +79,10 @@ def test_xyzz_bucket_accumulator(cn, cid):
 
     pts = [synth.point(c, i, seed=72) for i in range(40)]
     pairs = [(pts[i], pts[i + 1]) for i in range(0, 36, 2)] + [(pts[0], pts[0]), (pts[1], M.affine_neg(c, pts[1])), (None, pts[2]), (pts[5], pts[5])]
+    # every fourth entry (index = 2 mod 4) is summed by the general XYZZ addition: its exceptional cases at such indices too
+    pairs += [(pts[1], M.affine_neg(c, pts[1])), (pts[6], pts[7]), (pts[8], pts[9]), (pts[10], pts[11]), (None, pts[2]), (pts[12], pts[13]),
+              (pts[14], pts[15]), (pts[16], pts[17]), (pts[8], pts[8])]
+    assert [i for i, (a, b) in enumerate(pairs) if i % 4 == 2 and (a is None or a == b or a == M.affine_neg(c, b))] == [18, 22, 26, 30]
     pin = b"".join(b"".join(fe(v) for v in xyzz(a)) for a, _ in pairs)
     qin = b"".join(fe(b[0]) + fe(b[1]) for _, b in pairs)
     out = outbuf(3 * nb * len(pairs))
