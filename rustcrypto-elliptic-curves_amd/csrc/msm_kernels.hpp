@@ -780,20 +780,23 @@ __global__ void __launch_bounds__(64) level0_kernel(const Xyzz<C>* bucketsX, con
   constexpr int M = Geo<CB>::M;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= total) return;
-  Jac<C> run, wt, bj;
-  jac::set_infinity<C>(run);
+  Xyzz<C> run, wt;                                 // the buckets are XYZZ: the running sums stay in that form (12M + 2S per addition)
+  xyzz_set_infinity<C>(run);
   wt = run;
 #pragma unroll 1
   for (int t = M - 1; t >= 0; t--) {
     const size_t b = (size_t)s * M + t;
     if (offsets[b + 1] != offsets[b]) {            // an empty bucket was never written
-      load_xyzz_as_jacobian<C>(bj, &bucketsX[b]);
-      pt_add<C>(run, run, bj);
+      const Xyzz<C> bj = bucketsX[b];
+      xyzz_add<C>(run, bj);
     }
-    pt_add<C>(wt, wt, run);
+    xyzz_add<C>(wt, run);
   }
-  out_t[s] = run;
-  out_w[s] = wt;
+  Jac<C> r;
+  xyzz_to_jacobian<C>(r, run);
+  out_t[s] = r;
+  xyzz_to_jacobian<C>(r, wt);
+  out_w[s] = r;
 }
 // an M-ary level: children i = 0 .. M-1 of `size` = 2^log_size buckets each: T' = sum T_i, W' = sum W_i + size sum i T_i
 // (running sums from the top: run += T_i, acc += run for i = M-1 .. 1)
