@@ -18,9 +18,12 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
   roofline      the dominant kernel against its bound.  This path is integer-VALU bound (no MFMA,
                 ~0.2 % of HBM): achieved/peak are 32x32-bit multiply-accumulates per second.
                 `peak` is the datasheet half-rate figure, `peak_measured` the v_mad_u64_u32 issue rate
-                measured on this GPU in this run (tools/ubench/peak.hip), `valu_busy_pct` and `traffic`
-                come from the committed rocprofv3 PMC summary (profiles/pmc_summary.json) of this
-                command; the HBM view of the same kernel is under roofline["hbm"].
+                measured on this GPU in this run (tools/ubench/peak.hip).  `traffic` and everything under
+                roofline["pmc"] are NOT measured by this run: they are read from the committed rocprofv3
+                PMC summary of this command (profiles/pmc_summary_r*_<workload>.json) and roofline["pmc"]
+                says which file, which commit it was profiled at and whether the kernel sources of this
+                tree still hash to what was profiled; at N > 1 they are left out.  The HBM view of the
+                same kernel is under roofline["hbm"].
   cpu_baseline  the C restatement of the reference CPU path (oracle/ecoracle.c, "port": rustc is not
                 available) timed on this box's host cores on a bounded sample of the same workload
                 (median of 5, all cores and single thread), and used to check the GPU output of that
@@ -84,7 +87,7 @@ WORKLOADS = {
                          bytes_per_unit=32 + 64 + 65, kernel="k256_mul_fast_kernel<32,4>", pmc_match="k256_mul_fast_kernel",
                          desc="k256 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
     "p256_fixedbase": dict(curve="p256", cid=1, log2n=24, fixed=True, msm=False, metric="p256 fixed-base (mul_by_generator) scalar-muls/sec", unit="scalar-muls/s",
-                           bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,26,64,4>", pmc_match="mul_wide_kernel",
+                           bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,26,64,4>", pmc_match="P256Params>, 26, 64, 4",
                            desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
     "p384_varbase": dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
                          bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,4>", pmc_match="vb::mul_kernel",
@@ -293,21 +296,34 @@ def measure_peak(device):
     return a.value, b.value
 
 
-def pmc_summary(match, log2n, default_size):
-    """Counters of the committed rocprofv3 PMC passes for this kernel (profiles/pmc_summary*.json), at the config's own size only."""
-    if log2n != default_size:
-        return {}
+def csrc_sha16():
+    """Hash of the kernel sources (csrc/*): ties a committed PMC summary to the code it was profiled on."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_summary*.json")), reverse=True):
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "rustcrypto-elliptic-curves_amd", "csrc", "*"))):
+        if os.path.isfile(path):
+            h.update(os.path.basename(path).encode())
+            with open(path, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary(workload, log2n, default_size):
+    """The committed rocprofv3 PMC summary of this workload (profiles/pmc_summary_r*_<workload>.json, written by
+    tools/profile_workload.sh), at the config's own size only; the newest round wins.  -> (summary, file name)"""
+    if log2n != default_size:
+        return {}, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_summary_r*_%s.json" % workload)), reverse=True):
         try:
             with open(path) as f:
                 js = json.load(f)
         except Exception:
             continue
-        for ent in (js if isinstance(js, list) else [js]):
-            if ent.get("kernel_match") and (ent["kernel_match"] in match or match in ent["kernel_match"]):
-                return ent
-    return {}
+        if js.get("workload") == workload:
+            return js, os.path.relpath(path, ROOT)
+    return {}, None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -351,6 +367,21 @@ def run_workload(env, name, log2n, steps, warmup, schedule, cpu):
         bad = (torch.arange(first, first + n, device=dev) % ECDSA_CORRUPT_EVERY) == 0
         d_sig[bad, -1] ^= 1
     torch.cuda.synchronize()
+    table = None
+    if wl["fixed"]:
+        # the generator table is built (and its memory taken) by the first call of a size class: outside the timed region,
+        # but on the record - first-call time, steady-state time of the same call, and what the context holds afterwards
+        t0 = time.perf_counter()
+        cv.mul_device(d_s, None, d_o, n, d_out_inf=d_i)
+        ctx.synchronize()
+        first_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        cv.mul_device(d_s, None, d_o, n, d_out_inf=d_i)
+        ctx.synchronize()
+        again_ms = (time.perf_counter() - t0) * 1e3
+        tb, tw = ctx.fb_table_bytes(wl["curve"])
+        table = {"table_bytes": tb, "widest_window_bits": tw, "first_call_ms": first_ms, "table_build_ms": max(0.0, first_ms - again_ms),
+                 "note": "built by the first call of this size class, outside the timed region; kept by the context"}
     d_part = torch.empty((3 * nb,), dtype=torch.uint8, device=dev)
     d_all = torch.empty((max(world, 1), 3 * nb), dtype=torch.uint8, device=dev)
     d_fold = torch.empty((max(world, 1), 3 * nb), dtype=torch.uint8, device=dev)       # scratch of the fold of the gathered points
@@ -466,10 +497,10 @@ def run_workload(env, name, log2n, steps, warmup, schedule, cpu):
     del d_s, d_p, d_o, d_i
     torch.cuda.empty_cache()
     return {"name": name, "n": n, "log2n": log2n, "elapsed": elapsed, "kernel_ms": kernel_ms / steps, "steps": steps, "parity": bool(parity), "checked": checked,
-            "value": world * n * steps / elapsed}
+            "value": world * n * steps / elapsed, "table": table}
 
 
-def roofline_for(name, res, schedule, peak_meas, pair_meas):
+def roofline_for(name, res, schedule, peak_meas, pair_meas, world=1):
     wl = WORKLOADS[name]
     key = name if name != "k256_varbase" else "k256_varbase_" + schedule
     m_cnt, s_cnt = WORK[key]
@@ -481,16 +512,28 @@ def roofline_for(name, res, schedule, peak_meas, pair_meas):
     n = res["n"]
     achieved = n * mac_conv / kernel_s / 1e12
     issued = n * mac_issued / kernel_s / 1e12
-    pmc = pmc_summary(wl["pmc_match"], res["log2n"], wl["log2n"]) if schedule == "fast" else {}
+    pmc, pmc_file = pmc_summary(name, res["log2n"], wl["log2n"]) if (schedule == "fast" and world == 1) else ({}, None)
     ctr = pmc.get("counters_per_launch", {})
-    valu_busy = None
-    if "SQ_ACTIVE_INST_VALU" in ctr and "GRBM_GUI_ACTIVE" in ctr:
-        # gfx94x formula of the derived metric (the guide: gfx950 falls back to it): busy VALU cycles over SIMD cycles;
-        # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_ACTIVE_INST_VALU counts quad-cycles over all 1024 SIMDs
-        # (the formula prices every VALU instruction at 4 cycles; moves and plain adds issue faster on gfx950, so a kernel that
-        # never leaves the VALU can read a few per cent above 100: `valu_cycles_per_inst` is the measured average)
-        valu_busy = 100.0 * ctr["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (ctr["GRBM_GUI_ACTIVE"] / 8)
+    # SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU to the last digit on this stack (it counts instructions, not busy cycles),
+    # so instructions x 4 / SIMD cycles is the share of 4-cycle ISSUE SLOTS the VALU instructions would fill - not a busy
+    # measurement (moves and plain adds issue faster than one per 4 cycles: the MSM reads 105 %).  What the counters do
+    # say about stalls is SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, the share of wave-cycles spent waiting to issue.
+    issue_slots = None
+    if "SQ_INSTS_VALU" in ctr and "GRBM_GUI_ACTIVE" in ctr:
+        issue_slots = 100.0 * ctr["SQ_INSTS_VALU"] * 4 / 1024 / (ctr["GRBM_GUI_ACTIVE"] / 8)
     valu_cpi = (ctr["GRBM_GUI_ACTIVE"] / 8 * 1024 / ctr["SQ_INSTS_VALU"]) if ("SQ_INSTS_VALU" in ctr and "GRBM_GUI_ACTIVE" in ctr) else None
+    stall = (ctr["SQ_WAIT_INST_ANY"] / ctr["SQ_WAVE_CYCLES"]) if ("SQ_WAIT_INST_ANY" in ctr and ctr.get("SQ_WAVE_CYCLES")) else None
+    pmc_obj = None
+    if pmc:
+        kt = pmc.get("kernel_trace") or {}
+        pmc_obj = {"source": pmc_file, "profiled_at_commit": pmc.get("commit"), "profiled_csrc_sha16": pmc.get("csrc_sha16"),
+                   "csrc_sha16_of_this_tree": csrc_sha16(), "kernel_sources_unchanged_since_profile": pmc.get("csrc_sha16") == csrc_sha16(),
+                   "kernel_match": pmc.get("kernel_match"), "profiled_kernel_ms": (kt.get("avg_ns") / 1e6 if kt.get("avg_ns") else None),
+                   "hbm_bytes_per_launch": pmc.get("hbm_bytes_per_launch"), "traffic_over_algorithmic": (pmc["hbm_bytes_per_launch"] / (n * wl["bytes_per_unit"])
+                                                                                                      if pmc.get("hbm_bytes_per_launch") else None),
+                   "l2_hit_rate": pmc.get("l2_hit_rate"), "valu_insts_per_launch": ctr.get("SQ_INSTS_VALU"),
+                   "valu_issue_slots_pct": issue_slots, "valu_cycles_per_inst": valu_cpi, "issue_stall_frac": stall,
+                   "note": "read from the committed summary, not measured by this run"}
     alg_bytes = n * wl["bytes_per_unit"]
     r = {
         "bound": "valu", "achieved": achieved, "peak": PEAK_TMACS, "unit": "TMAC/s (32x32+64 v_mad_u64_u32)", "frac": achieved / PEAK_TMACS,
@@ -500,8 +543,7 @@ def roofline_for(name, res, schedule, peak_meas, pair_meas):
         "achieved_issued": issued, "frac_issued": issued / PEAK_TMACS,
         "peak_measured": peak_meas, "frac_of_peak_measured": (achieved / peak_meas if peak_meas else None),
         "mac_pair_peak_measured": pair_meas, "frac_of_mac_pair_peak": (issued / pair_meas if pair_meas else None),
-        "valu_busy_pct": valu_busy, "valu_cycles_per_inst": valu_cpi,
-        "valu_insts_per_launch": ctr.get("SQ_INSTS_VALU"),
+        "pmc": pmc_obj,
         "hbm": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": alg_bytes / kernel_s / 1e9 / PEAK_HBM_GBS, "bytes_per_unit": wl["bytes_per_unit"]},
     }
@@ -528,6 +570,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs 3, 4, 5 after the headline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse several ranks on one GPU)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1: initialise a world-size-1 process group all the same, so that the split-MSM step runs its collective branch "
+                         "(RCCL all_gather_into_tensor on device tensors + the device fold) on a one-GPU box")
     ap.add_argument("--schedule", choices=["fast", "ref"], default="fast",
                     help="fast = throughput schedule (affine result specified); ref = reference-faithful schedule (exact XYZ)")
     args = ap.parse_args()
@@ -554,7 +599,7 @@ def main():
         for o in others:            # small untimed-grade samples: parity of the other configs (and a rough rate)
             w2 = WORKLOADS[o]
             s2 = min(1 << w2["log2n"], {"k256": 16384, "p256": 2048, "p384": 1024}[w2["curve"]] * procs)
-            cpu_others[o] = run_cpu_baseline(s2, procs, w2["cid"], w2["fixed"], "msm" if w2["msm"] else "mul", 1 << w2["log2n"], reps=1, single=False)
+            cpu_others[o] = run_cpu_baseline(s2, procs, w2["cid"], w2["fixed"], "msm" if w2["msm"] else "mul", 1 << w2["log2n"], reps=5, single=True)
             cpu_others[o]["sample"] = s2
 
     import torch
@@ -569,16 +614,23 @@ def main():
         local_rank %= ndev                  # gloo rehearsal: ranks share the card
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        if world > 1:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        else:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            dist.init_process_group(backend=args.backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
 
     ctx = ecgpu.Context(local_rank)
-    # One explicit stream for everything: torch's default stream has handle 0, which the C ABI reads as "the context's own
-    # stream" - a different, non-blocking stream that torch (and RCCL, which orders a collective against torch's CURRENT
-    # stream) would not be ordered with.  All device work of this script runs under `with torch.cuda.stream(stream)`.
+    # One explicit stream for everything (RCCL orders a collective against torch's CURRENT stream, the library launches on
+    # the stream it was given): all device work of this script runs under `with torch.cuda.stream(stream)`.
     stream = torch.cuda.Stream(device=local_rank)
     ctx.set_stream(stream.cuda_stream)
     env = {"torch": torch, "ecgpu": ecgpu, "ctx": ctx, "dev": torch.device("cuda", local_rank), "rank": rank, "world": world, "dist": dist,
@@ -609,15 +661,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"] % args.log2n,
                        "units_per_gpu_per_step": n,
-                       "parallelism": (("one sum split over %d GPU(s): per-rank bucket method, all-gather of one projective point per rank, fold on the device" % world)
+                       "parallelism": (("one sum split over %d GPU(s): per-rank bucket method, all-gather of one projective point per rank%s, fold on the device" % (
+                                            world, (" (%s, world %d)" % (args.backend, world)) if dist is not None else " (no process group at N = 1)"))
                                        if wl["msm"] else ("independent batches, %d GPU(s), no collective" % world)),
                        "schedule": ("reference-faithful (GLV + signed radix-16, RCB complete formulas, constant-time table scans, per-point inversion)" if args.schedule == "ref"
                                     else "throughput (GLV + signed radix-16, Jacobian, common-Z table, batched inversion)")
                        if args.workload == "k256_varbase" else "throughput schedule of this workload (DESIGN.md section 4)"},
             "parity_ok": res["parity"],
             "parity_checked": res["checked"],
-            "roofline": roofline_for(args.workload, res, args.schedule, peak_meas, pair_meas),
+            "roofline": roofline_for(args.workload, res, args.schedule, peak_meas, pair_meas, world),
         }
+        if res.get("table"):
+            line["generator_table"] = res["table"]
         if cpu is not None:
             line["cpu_baseline"] = {
                 "value": cpu["rate"], "unit": wl["unit"], "cores": cpu["procs"], "kind": "port",
@@ -635,7 +690,12 @@ def main():
                        "roofline": roofline_for(r["name"], r, "fast", peak_meas, pair_meas)}
                 c2 = cpu_others.get(r["name"])
                 if c2 is not None:
-                    ent["cpu_baseline"] = {"value": c2["rate"], "unit": w2["unit"], "cores": c2["procs"], "kind": "port", "sample": "first %d units, one pass" % c2["sample"]}
+                    ent["cpu_baseline"] = {"value": c2["rate"], "unit": w2["unit"], "cores": c2["procs"], "kind": "port",
+                                           "sample": "first %d units of the same seeded batch, %d single-threaded processes, each slice timed in %d chunks: median chunk rate" % (
+                                               c2["sample"], c2["procs"], c2["reps"]),
+                                           "single_thread": {"value": c2["single_rate"], "cores": 1, "median_of": c2["reps"]}, "wall_s": c2["wall_s"]}
+                if r.get("table"):
+                    ent["generator_table"] = r["table"]
                 line["other_configs"].append(ent)
         print(json.dumps(line), flush=True)
     if dist is not None:

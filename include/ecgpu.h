@@ -20,8 +20,9 @@
  *      projective point       : X || Y || Z (3*NB), homogeneous (x = X/Z), identity (0, 1, 0)
  *                               (k256 projective.rs:38-50, primeorder projective.rs:37-52).
  *  - `mem` says where the caller's buffers live: ECGPU_MEM_HOST (the library stages them
- *    through HBM) or ECGPU_MEM_DEVICE (pointers into this GPU's HBM, 16-byte aligned; the
- *    call is asynchronous on the context's stream).
+ *    through HBM) or ECGPU_MEM_DEVICE (pointers into this GPU's HBM, 4-byte aligned - ecgpu_msm
+ *    additionally wants its AFFINE points 16-byte aligned; the call is asynchronous on the
+ *    context's stream).
  *  - Every function returns 0 on success or a negative ecgpu_status; ecgpu_last_error() gives
  *    the text.  Arithmetic on valid inputs cannot fail.  Decoding failures (scalar >= n,
  *    coordinate >= p, point not on the curve) are reported per element by the *_validate
@@ -100,7 +101,12 @@ enum {
   /* ecgpu_mul_batch / ecgpu_lincomb_batch: the scalars are secret and only the group element is wanted (key generation:
    * PublicKey::from_secret_scalar is d G).  With points == NULL the multiplication runs on the constant-time fixed-base
    * kernel signing uses (every table entry read, complete additions; the result is the same point, not the reference's
-   * (X, Y, Z)); with a variable base point the flag selects the reference schedule, the constant-time one there is.
+   * (X, Y, Z)); with a variable base point (ECDH: elliptic_curve::ecdh::diffie_hellman) P-256 and P-384 run a dedicated
+   * constant-time kernel - signed 4-bit digits of min(k, n - k) by branch-free recoding, a masked scan over all eight
+   * entries of a per-lane affine table, Jacobian doublings and a mixed addition for every digit whose two special
+   * operands (empty accumulator, zero digit) are resolved by masks; the fold keeps every addition off the formula's
+   * exceptional cases for every k (csrc/varbase_ct.hpp has the argument) - 1.5x the reference schedule; secp256k1 takes
+   * the reference schedule (GLV and complete formulas), which is constant-time as well.
    * Staged host copies of the scalars are cleared as with ECGPU_EXACT_REFERENCE. */
   ECGPU_SECRET_SCALARS = 8u
 };
@@ -109,16 +115,51 @@ enum {
  * A context owns grow-only workspaces and, per curve, the generator tables it has needed so far (built on the device on
  * first use, kept until ecgpu_destroy): 270 KB for batches below 2^18, 36 MB from 2^18, 436 MB from 2^21, 5.9 GB
  * (13.7 GB for P-384) from 2^23 and 21.5 GB (secp256k1, P-256) from 2^24 results per call; the first call of a size class
- * pays the build (7 / 30 / 85 ms for the last three).  In the environment ECGPU_FB_MAX_WINDOW = 8 | 16 | 20 | 24 | 26 caps
- * the table width a context may build, ECGPU_FB_WINDOW pins one. */
+ * pays the build (7 / 30 / 85 ms for the last three).  A table that cannot be allocated (hipErrorOutOfMemory) or would
+ * exceed ECGPU_OPT_FB_MEMORY_BUDGET is not an error: the call steps down to the next narrower table (26 -> 24 -> 20 -> 16 -> 8 bits) and the context remembers the
+ * width that fitted as its cap (ECGPU_OPT_FB_MAX_WINDOW shows and resets it).  ecgpu_fb_table_bytes reports what a context
+ * holds.  No entry point reads the process environment; the tuning knobs are per-context options (ecgpu_set_option). */
 int ecgpu_create(ecgpu_ctx** ctx, int device_index);
 void ecgpu_destroy(ecgpu_ctx* ctx);
-/* Use the caller's HIP stream (hipStream_t) for all launches; NULL = the context's own stream.  Calls on one context
- * share its scratch buffers and lazily built tables, so they are serialised by the context's lock and, across a stream
- * switch, by an event: everything queued on the previous stream is ordered before anything queued on the new one. */
+/* Streams.  A new context launches on a stream of its own, created as a BLOCKING stream: it synchronises with the legacy
+ * default stream (handle 0, PyTorch's default stream) the way every ordinary HIP stream does, so a caller that prepares
+ * inputs on the default stream and calls the library without further ado is ordered correctly.
+ *   ecgpu_set_stream(ctx, s)      all later launches go to the caller's hipStream_t s.  s = NULL is the legacy default
+ *                                 stream itself, as for every HIP API (it is NOT "the context's own stream").
+ *   ecgpu_use_own_stream(ctx)     back to the context's own stream.
+ * Calls on one context share its scratch buffers and lazily built tables, so they are serialised by the context's lock
+ * and, across a stream switch, by an event: everything queued on the previous stream is ordered before anything queued
+ * on the new one.  The previous stream must still be alive at the switch; if recording on it fails the library falls
+ * back to hipDeviceSynchronize and installs the new stream all the same. */
 int ecgpu_set_stream(ecgpu_ctx* ctx, void* hip_stream);
+int ecgpu_use_own_stream(ecgpu_ctx* ctx);
 int ecgpu_synchronize(ecgpu_ctx* ctx);
+/* Text of the context's last error.  The pointer form reads the context's buffer without a lock (single-threaded use);
+ * ecgpu_last_error_copy copies it under the lock that writers take, for contexts shared between threads. */
 const char* ecgpu_last_error(const ecgpu_ctx* ctx);
+int ecgpu_last_error_copy(ecgpu_ctx* ctx, char* buf, size_t cap);
+
+/* Per-context tuning and test knobs (none is needed for correct results; defaults in brackets).  Values outside the
+ * listed sets are refused with ECGPU_ERR_ARG. */
+typedef enum ecgpu_option {
+  ECGPU_OPT_FB_WINDOW = 0,        /* pin the generator-table window width: 8 | 16 | 20 | 24 | 26, 0 = the size rule [0] */
+  ECGPU_OPT_FB_MAX_WINDOW = 1,    /* widest generator table the size rule may build: 8 | 16 | 20 | 24 | 26 [26]; lowered by
+                                     the library itself when an allocation fails, setting it again lifts that */
+  ECGPU_OPT_MSM_WINDOW_BITS = 2,  /* bucket-method window: 16 | 19, 0 = the size rule [0] */
+  ECGPU_OPT_MSM_SLAB_TERMS = 3,   /* terms per slab of a large sum, 1024 .. the window's maximum, 0 = that maximum [0] */
+  ECGPU_OPT_MSM_SMALL_PATH = 4,   /* 1: sums below 2^13 terms run as scalar multiplications and a tree sum, 0: always buckets [1] */
+  ECGPU_OPT_MSM_ROUNDS = 5,       /* bucket-sum runs per resident lane, 1 .. 64, 0 = default [0] */
+  ECGPU_OPT_K256_WAVES = 6,       /* occupancy variant of the secp256k1 variable-base kernel: 3 | 4 waves per SIMD [4] */
+  ECGPU_OPT_FB_MEMORY_BUDGET = 7, /* bytes of device memory the generator tables of ONE curve may take in this context,
+                                     0 = no budget [0].  A table that would exceed it is treated exactly like one whose
+                                     allocation failed: the call steps down to the next narrower width. */
+  ECGPU_OPT_COUNT_ = 8
+} ecgpu_option;
+int ecgpu_set_option(ecgpu_ctx* ctx, int option, int64_t value);
+int ecgpu_get_option(ecgpu_ctx* ctx, int option, int64_t* value);
+/* Device memory held by the generator tables of `curve` in this context (all widths built so far), and the widest window
+ * among them (0: none built yet).  Either output may be NULL. */
+int ecgpu_fb_table_bytes(ecgpu_ctx* ctx, int curve, size_t* bytes, int* widest_window);
 const char* ecgpu_version(void);
 /* NB for a curve (32 / 32 / 48), 0 for an unknown curve. */
 size_t ecgpu_field_bytes(int curve);
@@ -218,6 +259,18 @@ int ecgpu_to_bytes_batch(ecgpu_ctx* ctx, int curve, const uint8_t* points, int p
                          size_t n, int mem);
 int ecgpu_from_bytes_batch(ecgpu_ctx* ctx, int curve, const uint8_t* in, uint8_t* out_xy, uint8_t* ok,
                            size_t n, int mem);
+
+/* ToEncodedPoint::to_encoded_point(compress) / FromEncodedPoint::from_encoded_point (k256 affine.rs:241-284, primeorder
+ * affine.rs:161-195, 340-358) with fixed-width records so that a batch is one dense array:
+ *   compress = 0: 1 + 2 field_bytes per point, 0x04 || x || y;   compress = 1: 1 + field_bytes, 0x02 | 0x03 || x.
+ * The identity, one byte 0x00 in SEC1, is tag 0x00 followed by zero padding.
+ * ecgpu_sec1_decode_batch reads records of `record_bytes` = 1 + 2 field_bytes (tags 0x04; 0x02 / 0x03 / 0x05 with x and
+ * zero padding; 0x00 and zeros) or 1 + field_bytes (what ecgpu_from_bytes_batch takes) and applies the reference's checks:
+ * coordinates below p, the curve equation for 0x04, a square root for the compressed forms.  ok[i] = 0 and zeros otherwise. */
+int ecgpu_sec1_encode_batch(ecgpu_ctx* ctx, int curve, const uint8_t* points, int point_format, int compress, uint8_t* out,
+                            size_t n, int mem);
+int ecgpu_sec1_decode_batch(ecgpu_ctx* ctx, int curve, const uint8_t* in, size_t record_bytes, uint8_t* out_xy, uint8_t* ok,
+                            size_t n, int mem);
 
 /* ---- ECDSA over the path (the callers of mul_by_generator / lincomb) ---------------------------
  * VerifyPrimitive::verify_prehashed / SignPrimitive::try_sign_prehashed; the primitives are the

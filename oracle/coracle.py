@@ -68,6 +68,7 @@ def synth_points(curve, n, seed, first=0):
 
 
 def point_op(curve, op, p, q=None):
+    """op 0: add (q projective), 1: double, 2: add_mixed (q affine x || y, zeros = identity) -> exact (X, Y, Z) bytes"""
     p = np.ascontiguousarray(p, dtype=np.uint8)
     q = None if q is None else np.ascontiguousarray(q, dtype=np.uint8)
     out = np.zeros_like(p)

@@ -216,6 +216,28 @@ static k256_pt k256_add(const k256_pt* p, const k256_pt* q) { /* :96-161 */
   u = fe5_mul(&yz_pairs, &yy_p_bzz3); v = fe5_mul(&xx3, &xy_pairs); t = fe5_add(&u, &v); r.z = fe5_normalize_weak(&t);
   return r;
 }
+/* add_mixed, projective.rs:164-221 (RCB Algorithm 8); the affine operand is (x, y, infinity) */
+static k256_pt k256_add_mixed(const k256_pt* p, const fe5* qx, const fe5* qy, int q_inf) {
+  fe5 xx = fe5_mul(&p->x, qx), yy = fe5_mul(&p->y, qy);
+  fe5 t, u, v;
+  t = fe5_add(&xx, &yy); fe5 n_xx_yy = fe5_negate(&t, 2);
+  u = fe5_add(&p->x, &p->y); v = fe5_add(qx, qy); t = fe5_mul(&u, &v); fe5 xy_pairs = fe5_add(&t, &n_xx_yy);
+  t = fe5_mul(qy, &p->z); fe5 yz_pairs = fe5_add(&t, &p->y);
+  t = fe5_mul(qx, &p->z); fe5 xz_pairs = fe5_add(&t, &p->x);
+  fe5 bzz = fe5_mul_single(&p->z, 7);
+  t = fe5_double(&bzz); t = fe5_add(&t, &bzz); fe5 bzz3 = fe5_normalize_weak(&t);
+  t = fe5_negate(&bzz3, 1); fe5 yy_m_bzz3 = fe5_add(&yy, &t);
+  fe5 yy_p_bzz3 = fe5_add(&yy, &bzz3);
+  t = fe5_mul_single(&yz_pairs, 7); fe5 byz = fe5_normalize_weak(&t);
+  t = fe5_double(&byz); t = fe5_add(&t, &byz); fe5 byz3 = fe5_normalize_weak(&t);
+  t = fe5_double(&xx); fe5 xx3 = fe5_add(&t, &xx);
+  t = fe5_double(&xx3); t = fe5_add(&t, &xx3); t = fe5_normalize_weak(&t); t = fe5_mul_single(&t, 7); fe5 bxx9 = fe5_normalize_weak(&t);
+  k256_pt r;
+  u = fe5_mul(&xy_pairs, &yy_m_bzz3); v = fe5_mul(&byz3, &xz_pairs); v = fe5_negate(&v, 1); t = fe5_add(&u, &v); r.x = fe5_normalize_weak(&t);
+  u = fe5_mul(&yy_p_bzz3, &yy_m_bzz3); v = fe5_mul(&bxx9, &xz_pairs); t = fe5_add(&u, &v); r.y = fe5_normalize_weak(&t);
+  u = fe5_mul(&yz_pairs, &yy_p_bzz3); v = fe5_mul(&xx3, &xy_pairs); t = fe5_add(&u, &v); r.z = fe5_normalize_weak(&t);
+  return q_inf ? *p : r;                       /* :219 conditional_assign(self, other.is_identity()) */
+}
 static k256_pt k256_double(const k256_pt* p) { /* :225-274 */
   fe5 yy = fe5_sqr(&p->y), zz = fe5_sqr(&p->z);
   fe5 t = fe5_mul(&p->x, &p->y); fe5 xy2 = fe5_double(&t);
@@ -607,6 +629,27 @@ static mpt mpt_add(const mcurve* c, const mpt* p, const mpt* q) { /* point_arith
   MUL(t0, yy_p_bzz3, yy_m_bzz3); MUL(t1, xx3_m_zz3, bxz3_part); ADD(r.y, t0, t1);
   MUL(t0, yy_m_bzz3, yz_pairs); MUL(t1, xy_pairs, xx3_m_zz3); ADD(r.z, t0, t1);
   return r;
+}
+static mpt mpt_add_mixed(const mcurve* c, const mpt* p, const mfe* qx, const mfe* qy, int q_inf) { /* point_arithmetic.rs:247-277 */
+  mfe B; memset(&B, 0, sizeof(B)); memcpy(B.w, c->b, sizeof(u64) * c->nl);
+  mfe xx, yy, t0, t1, xy_pairs, yz_pairs, xz_pairs;
+  MUL(xx, p->x, *qx); MUL(yy, p->y, *qy);
+  ADD(t0, p->x, p->y); ADD(t1, *qx, *qy); MUL(xy_pairs, t0, t1); ADD(t0, xx, yy); SUB(xy_pairs, xy_pairs, t0);
+  MUL(t0, *qy, p->z); ADD(yz_pairs, t0, p->y);
+  MUL(t0, *qx, p->z); ADD(xz_pairs, t0, p->x);
+  mfe bz_part, bz3_part, yy_m_bzz3, yy_p_bzz3, z3, bxz_part, bxz3_part, xx3_m_zz3;
+  MUL(t0, B, p->z); SUB(bz_part, xz_pairs, t0);
+  ADD(t0, bz_part, bz_part); ADD(bz3_part, t0, bz_part);
+  SUB(yy_m_bzz3, yy, bz3_part); ADD(yy_p_bzz3, yy, bz3_part);
+  ADD(t0, p->z, p->z); ADD(z3, t0, p->z);
+  MUL(t0, B, xz_pairs); ADD(t1, z3, xx); SUB(bxz_part, t0, t1);
+  ADD(t0, bxz_part, bxz_part); ADD(bxz3_part, t0, bxz_part);
+  ADD(t0, xx, xx); ADD(t0, t0, xx); SUB(xx3_m_zz3, t0, z3);
+  mpt r;
+  MUL(t0, yy_p_bzz3, xy_pairs); MUL(t1, yz_pairs, bxz3_part); SUB(r.x, t0, t1);
+  MUL(t0, yy_p_bzz3, yy_m_bzz3); MUL(t1, xx3_m_zz3, bxz3_part); ADD(r.y, t0, t1);
+  MUL(t0, yy_m_bzz3, yz_pairs); MUL(t1, xy_pairs, xx3_m_zz3); ADD(r.z, t0, t1);
+  return q_inf ? *p : r;                       /* :275 conditional_assign(lhs, rhs.is_identity()) */
 }
 static mpt mpt_double(const mcurve* c, const mpt* p) { /* point_arithmetic.rs:286-317 */
   mfe B; memset(&B, 0, sizeof(B)); memcpy(B.w, c->b, sizeof(u64) * c->nl);
@@ -1034,14 +1077,18 @@ int eco_ecdsa_sign_batch(int curve, const u8* d, const u8* k, const u8* z, u8* s
   return 0;
 }
 
-/* point add / double with exact projective outputs (for cross-checking the model) */
-int eco_point_op(int curve, int op, const u8* p_xyz, const u8* q_xyz, u8* out_xyz, size_t n) {
+/* point add (op 0, q = X || Y || Z), double (op 1), add_mixed (op 2, q = affine x || y, all zero = AffinePoint::IDENTITY)
+ * with exact projective outputs */
+int eco_point_op(int curve, int op, const u8* p_xyz, const u8* q, u8* out_xyz, size_t n) {
   const int nb = curve == 2 ? 48 : 32;
   for (size_t i = 0; i < n; i++) {
+    int q_inf = 1;
+    if (op == 2) for (int j = 0; j < 2 * nb; j++) if (q[2 * nb * i + j]) { q_inf = 0; break; }
     if (curve == 0) {
       k256_pt a, b, r;
       fe5_from_bytes(&a.x, p_xyz + 96 * i); fe5_from_bytes(&a.y, p_xyz + 96 * i + 32); fe5_from_bytes(&a.z, p_xyz + 96 * i + 64);
-      if (op == 0) { fe5_from_bytes(&b.x, q_xyz + 96 * i); fe5_from_bytes(&b.y, q_xyz + 96 * i + 32); fe5_from_bytes(&b.z, q_xyz + 96 * i + 64); r = k256_add(&a, &b); }
+      if (op == 0) { fe5_from_bytes(&b.x, q + 96 * i); fe5_from_bytes(&b.y, q + 96 * i + 32); fe5_from_bytes(&b.z, q + 96 * i + 64); r = k256_add(&a, &b); }
+      else if (op == 2) { fe5_from_bytes(&b.x, q + 64 * i); fe5_from_bytes(&b.y, q + 64 * i + 32); r = k256_add_mixed(&a, &b.x, &b.y, q_inf); }
       else r = k256_double(&a);
       k256_pt_to_bytes(out_xyz + 96 * i, &r);
     } else {
@@ -1050,7 +1097,8 @@ int eco_point_op(int curve, int op, const u8* p_xyz, const u8* q_xyz, u8* out_xy
       mpt a, b, r; memset(&a, 0, sizeof(a)); memset(&b, 0, sizeof(b));
       const u8* s = p_xyz + 3 * nb * i;
       mfe_from_bytes(c, &a.x, s); mfe_from_bytes(c, &a.y, s + nb); mfe_from_bytes(c, &a.z, s + 2 * nb);
-      if (op == 0) { s = q_xyz + 3 * nb * i; mfe_from_bytes(c, &b.x, s); mfe_from_bytes(c, &b.y, s + nb); mfe_from_bytes(c, &b.z, s + 2 * nb); r = mpt_add(c, &a, &b); }
+      if (op == 0) { s = q + 3 * nb * i; mfe_from_bytes(c, &b.x, s); mfe_from_bytes(c, &b.y, s + nb); mfe_from_bytes(c, &b.z, s + 2 * nb); r = mpt_add(c, &a, &b); }
+      else if (op == 2) { s = q + 2 * nb * i; mfe_from_bytes(c, &b.x, s); mfe_from_bytes(c, &b.y, s + nb); r = mpt_add_mixed(c, &a, &b.x, &b.y, q_inf); }
       else r = mpt_double(c, &a);
       u8* o = out_xyz + 3 * nb * i;
       mfe_to_bytes(c, o, &r.x); mfe_to_bytes(c, o + nb, &r.y); mfe_to_bytes(c, o + 2 * nb, &r.z);

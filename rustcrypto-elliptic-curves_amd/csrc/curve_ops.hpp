@@ -1,6 +1,5 @@
 // Generic kernel launchers over a curve traits class; instantiated once per curve in ops_*.hip.
 #pragma once
-#include <stdlib.h>
 #include "ecgpu_internal.hpp"
 #include "kernels.hpp"
 #include "fixedbase.hpp"
@@ -58,6 +57,11 @@ struct CurveOps {
     return 0;
   }
   // fixed-base table T[j][d-1] = d 2^(8j) G (fixedbase.hpp), built once per context
+  static constexpr int FB_NOMEM = 100;          // internal: a table did not fit, the caller steps down a width
+  static void fb_account(ecgpu_ctx* c, size_t bytes, int window) {
+    c->fb_bytes[C::ID] += bytes;
+    if (window > c->fb_widest[C::ID]) c->fb_widest[C::ID] = window;
+  }
   static int ensure_fb_table(ecgpu_ctx* c) {
     if (c->fb_table[C::ID]) return 0;
     const int total = fb::nwin<C>() * fb::ENTRIES;
@@ -74,6 +78,7 @@ struct CurveOps {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->fb_table[C::ID] = tab;
     ttab.p = nullptr;                  // owned by the context from here on
+    fb_account(c, sizeof(AffEntry<C>) * total, fb::W);
     return 0;
   }
   // wide tables TW[j][d-1] = d 2^(WB j) G, 2^(WB-1) entries per window, built by multiplying the scalars d 2^(WB j)
@@ -87,7 +92,7 @@ struct CurveOps {
     int rc = ensure_fb_table(c);
     if (rc) return rc;
     if constexpr (WB > 20) {
-      if ((rc = ensure_fb_wide_table<20>(c, &c->fb20_table[C::ID]))) return rc;
+      if ((rc = ensure_fb_wide_table<20>(c, &c->fb20_table[C::ID]))) return rc;       // FB_NOMEM passes through
     }
     const size_t total = (size_t)fb::nwin_wide<C, WB>() * fb::wide_entries<WB>();
     const size_t chunk = total < ((size_t)1 << 24) ? total : ((size_t)1 << 24);     // entries per pass: at most 1.5 GB (2.3 GB for p384) of scratch
@@ -95,9 +100,19 @@ struct CurveOps {
       void* p = nullptr;
       ~Tmp() { if (p) (void)hipFree(p); }
     } tks, txy, ttab;
-    HIPCHK(c, hipMalloc(&tks.p, chunk * C::NB));
-    HIPCHK(c, hipMalloc(&txy.p, chunk * 2 * C::NB));
-    HIPCHK(c, hipMalloc(&ttab.p, total * sizeof(AffEntry<C>)));
+    // a table that does not fit - the context's budget or the device's memory - is not an error: the caller falls back to
+    // the next narrower width
+    if (c->opt[ECGPU_OPT_FB_MEMORY_BUDGET] > 0 && c->fb_bytes[C::ID] + total * sizeof(AffEntry<C>) > (size_t)c->opt[ECGPU_OPT_FB_MEMORY_BUDGET]) return FB_NOMEM;
+    {
+      hipError_t e = hipMalloc(&tks.p, chunk * C::NB);
+      if (e == hipSuccess) e = hipMalloc(&txy.p, chunk * 2 * C::NB);
+      if (e == hipSuccess) e = hipMalloc(&ttab.p, total * sizeof(AffEntry<C>));
+      if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();         // not sticky: the next launch check must not report it
+        return FB_NOMEM;
+      }
+      if (e != hipSuccess) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "generator table (%d-bit windows): %s", WB, hipGetErrorString(e));
+    }
     void *ks = tks.p, *xy = txy.p;
     AffEntry<C>* tab = (AffEntry<C>*)ttab.p;
     for (size_t e0 = 0; e0 < total; e0 += chunk) {
@@ -115,6 +130,7 @@ struct CurveOps {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *slot = tab;
     ttab.p = nullptr;                  // the context owns the table now; the two scratch buffers go with this scope
+    fb_account(c, total * sizeof(AffEntry<C>), WB);
     return 0;
   }
   template <int WB>
@@ -127,18 +143,27 @@ struct CurveOps {
     return 1;
   }
   static int mul_gen_fast(ecgpu_ctx* c, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
-    // ECGPU_FB_WINDOW = 8 / 16 / 20 / 24 / 26 pins one table width (measurements, small-memory processes);
-    // ECGPU_FB_MAX_WINDOW caps what the size rule may pick (default 26: 21.5 GB per 256-bit curve)
-    static const int forced = [] { const char* e = getenv("ECGPU_FB_WINDOW"); return e ? atoi(e) : 0; }();
-    static const int cap = [] { const char* e = getenv("ECGPU_FB_MAX_WINDOW"); const int v = e ? atoi(e) : 26; return v < 8 ? 8 : v; }();
+    // ECGPU_OPT_FB_WINDOW pins one table width (measurements, small-memory processes); ECGPU_OPT_FB_MAX_WINDOW caps what
+    // the size rule may pick (default 26: 21.5 GB per 256-bit curve)
+    const int forced = (int)c->opt[ECGPU_OPT_FB_WINDOW];
     // (P-384 stops at 24 bits: its 26-bit table would be 48 GB and measured 45.2 ms against 46.4 ms per 2^24 results)
     int wb = (n >= ((size_t)1 << 24) && C::NW <= 8) ? 26 : n >= ((size_t)1 << 23) ? 24 : n >= ((size_t)1 << 21) ? 20 : n >= ((size_t)1 << 18) ? 16 : 8;
-    if (wb > cap) wb = cap >= 26 ? 26 : cap >= 24 ? 24 : cap >= 20 ? 20 : cap >= 16 ? 16 : 8;
     if (forced) wb = forced;
-    if (wb == 26) return mul_gen_wide<26>(c, &c->fb26_table[C::ID], sc, out, out_fmt, out_inf, n);
-    if (wb == 24) return mul_gen_wide<24>(c, &c->fb24_table[C::ID], sc, out, out_fmt, out_inf, n);
-    if (wb == 20) return mul_gen_wide<20>(c, &c->fb20_table[C::ID], sc, out, out_fmt, out_inf, n);
-    if (wb == 16) return mul_gen_wide<16>(c, &c->fb16_table[C::ID], sc, out, out_fmt, out_inf, n);
+    // A table that cannot be allocated is not an error: step down to the next narrower one and remember the width that
+    // fitted as this context's cap, so that later calls do not try (and fail) a 21 GB allocation each time.
+    for (;;) {
+      const int cap = (int)c->opt[ECGPU_OPT_FB_MAX_WINDOW];
+      if (wb > cap) wb = cap;
+      int rc;
+      if (wb >= 26) rc = mul_gen_wide<26>(c, &c->fb26_table[C::ID], sc, out, out_fmt, out_inf, n);
+      else if (wb >= 24) rc = mul_gen_wide<24>(c, &c->fb24_table[C::ID], sc, out, out_fmt, out_inf, n);
+      else if (wb >= 20) rc = mul_gen_wide<20>(c, &c->fb20_table[C::ID], sc, out, out_fmt, out_inf, n);
+      else if (wb >= 16) rc = mul_gen_wide<16>(c, &c->fb16_table[C::ID], sc, out, out_fmt, out_inf, n);
+      else break;
+      if (rc != FB_NOMEM) return rc;
+      wb = wb >= 26 ? 24 : wb >= 24 ? 20 : wb >= 20 ? 16 : 8;
+      c->opt[ECGPU_OPT_FB_MAX_WINDOW] = wb;
+    }
     int rc = ensure_fb_table(c);
     if (rc) return rc;
     hipLaunchKernelGGL((fb::mul_kernel<C, 16, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc,
@@ -149,6 +174,7 @@ struct CurveOps {
   // k G for secret scalars: constant-time fixed-base kernel (fixedbase.hpp), one inversion per 8 results
   static int mul_gen_ct(ecgpu_ctx* c, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
     int rc = ensure_fb_wide_table<fb::CT_WB>(c, &c->fbct_table[C::ID]);
+    if (rc == FB_NOMEM) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "out of device memory for the 5-bit generator table");
     if (rc) return rc;
     constexpr int WAVES = C::NW > 8 ? 2 : (C::ID == 0 ? 3 : 4);       // what the complete addition's live set allows: 230 / 146 / 127 VGPRs
     hipLaunchKernelGGL((fb::mul_ct_kernel<C, 8, WAVES>), dim3(ecgpu_grid_for(c, n, WAVES)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)c->fbct_table[C::ID], out,
@@ -159,11 +185,18 @@ struct CurveOps {
   // curve-specific throughput kernels hook in here (specialised in ops_*.hip); returns 1 if it launched
   static int lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt,
                           uint8_t* out_inf, size_t n);
+  // constant-time variable base for secret scalars (varbase_ct.hpp; specialised in ops_*.hip); returns 1 if it launched
+  static int mul_ct(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf, size_t n);
   static int lincomb(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt, uint8_t* out_inf,
                      size_t n, unsigned flags) {
     if ((flags & ECGPU_SECRET_SCALARS) && !(flags & ECGPU_EXACT_REFERENCE)) {
       if (!pts && terms == 1) return mul_gen_ct(c, sc, out, out_fmt, out_inf, n);
-      flags |= ECGPU_EXACT_REFERENCE;              // variable base: the reference schedule is the constant-time one
+      if (pts && terms == 1) {
+        int rc = mul_ct(c, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
+        if (rc < 0) return rc;
+        if (rc == 1) return 0;
+      }
+      flags |= ECGPU_EXACT_REFERENCE;              // no dedicated kernel: the reference schedule is constant-time as well
     }
     if (!(flags & ECGPU_EXACT_REFERENCE)) {
       int rc = lincomb_fast(c, sc, pts, pt_fmt, terms, out, out_fmt, out_inf, n);
@@ -222,8 +255,8 @@ struct CurveOps {
     HIPCHK(c, hipGetLastError());
     return 0;
   }
-  // GroupEncoding::to_bytes of affine or projective points (projective input is batch-normalised first)
-  static int to_bytes(ecgpu_ctx* c, const u32* pts, int pt_fmt, uint8_t* out, size_t n) {
+  // GroupEncoding::to_bytes / ToEncodedPoint of affine or projective points (projective input is batch-normalised first)
+  static int sec1_to(ecgpu_ctx* c, const u32* pts, int pt_fmt, int uncompressed, uint8_t* out, size_t n) {
     const u32* xy = pts;
     const uint8_t* inf = nullptr;
     if (pt_fmt == FMT_PROJECTIVE) {
@@ -235,15 +268,18 @@ struct CurveOps {
       if ((rc = normalize(c, pts, t, ti, n))) return rc;
       xy = t; inf = ti;
     }
-    hipLaunchKernelGGL((sec1::to_bytes_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, xy, inf, out, n);
+    hipLaunchKernelGGL((sec1::to_bytes_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, xy, inf, out, n, uncompressed);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
-  static int from_bytes(ecgpu_ctx* c, const uint8_t* in, u32* out_xy, uint8_t* ok, size_t n) {
-    hipLaunchKernelGGL((sec1::from_bytes_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, in, out_xy, ok, n);
+  static int to_bytes(ecgpu_ctx* c, const u32* pts, int pt_fmt, uint8_t* out, size_t n) { return sec1_to(c, pts, pt_fmt, 0, out, n); }
+  static int sec1_encode(ecgpu_ctx* c, const u32* pts, int pt_fmt, int compress, uint8_t* out, size_t n) { return sec1_to(c, pts, pt_fmt, compress ? 0 : 1, out, n); }
+  static int sec1_decode(ecgpu_ctx* c, const uint8_t* in, size_t record_bytes, u32* out_xy, uint8_t* ok, size_t n) {
+    hipLaunchKernelGGL((sec1::from_bytes_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, in, out_xy, ok, n, (int)record_bytes);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
+  static int from_bytes(ecgpu_ctx* c, const uint8_t* in, u32* out_xy, uint8_t* ok, size_t n) { return sec1_decode(c, in, 1 + C::NB, out_xy, ok, n); }
   // ECDSA pipelines (ecdsa_kernels.hpp): the scalar multiplications run on the throughput kernels above
   static int ecdsa_reserve(ecgpu_ctx* c, size_t need) {
     if (need <= c->ecdsa_ws_cap) return 0;
@@ -348,7 +384,7 @@ struct CurveOps {
   }
   static const ecgpu_curve_ops* table() {
     static const ecgpu_curve_ops t = {field_op, point_op, point_eq, normalize, lincomb, msm, validate_scalars, validate_points,
-                                      decompress, synth_scalars, synth_points, to_bytes, from_bytes, ecdsa_verify, h2c_map, ecdsa_recover, schnorr_verify, ecdsa_sign};
+                                      decompress, synth_scalars, synth_points, to_bytes, from_bytes, sec1_encode, sec1_decode, ecdsa_verify, h2c_map, ecdsa_recover, schnorr_verify, ecdsa_sign};
     return &t;
   }
 };

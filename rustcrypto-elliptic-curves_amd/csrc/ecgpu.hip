@@ -10,7 +10,10 @@
 
 static int stage_reserve(ecgpu_ctx* c, int slot, size_t bytes) {
   if (bytes <= c->stage_cap[slot]) return 0;
-  if (c->stage[slot]) HIPCHK(c, hipFree(c->stage[slot]));
+  if (c->stage[slot]) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // work queued on the old buffer
+    HIPCHK(c, hipFree(c->stage[slot]));
+  }
   c->stage[slot] = nullptr;
   c->stage_cap[slot] = 0;
   size_t cap = bytes + bytes / 4 + 256;
@@ -182,7 +185,7 @@ int ecgpu_create(ecgpu_ctx** out, int device_index) {
   ecgpu_ctx* c = new ecgpu_ctx();
   c->device = device_index;
   c->num_cus = prop.multiProcessorCount;
-  if (hipSetDevice(device_index) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+  if (hipSetDevice(device_index) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming) != hipSuccess) {
     delete c;
@@ -223,17 +226,30 @@ void ecgpu_destroy(ecgpu_ctx* c) {
 
 // The per-context scratch (staging slots, table / MSM / ECDSA workspaces, lazily built tables) is shared by
 // consecutive calls, so work queued on the old stream must be ordered before anything the new stream does:
-// an event recorded on the old stream is waited for by the new one.
-int ecgpu_set_stream(ecgpu_ctx* c, void* s) {
-  if (!c) return ECGPU_ERR_ARG;
+// an event recorded on the old stream is waited for by the new one.  If the old stream cannot take the record any
+// more (the caller destroyed it), a device-wide synchronisation gives the same ordering; the new stream is installed
+// either way, so a context never stays pinned to a dead stream.
+static int switch_stream(ecgpu_ctx* c, hipStream_t next) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  hipStream_t next = s ? (hipStream_t)s : c->own_stream;
   if (next == c->stream) return ECGPU_OK;
-  HIPCHK(c, hipEventRecord(c->ev_switch, c->stream));
-  HIPCHK(c, hipStreamWaitEvent(next, c->ev_switch, 0));
+  hipError_t e = hipEventRecord(c->ev_switch, c->stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(next, c->ev_switch, 0);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();                  // not sticky: the next launch check must not report it
+    (void)hipDeviceSynchronize();
+  }
   c->stream = next;
   return ECGPU_OK;
+}
+// NULL is the legacy default stream, as for every HIP API (PyTorch's default stream has this handle)
+int ecgpu_set_stream(ecgpu_ctx* c, void* s) {
+  if (!c) return ECGPU_ERR_ARG;
+  return switch_stream(c, (hipStream_t)s);
+}
+int ecgpu_use_own_stream(ecgpu_ctx* c) {
+  if (!c) return ECGPU_ERR_ARG;
+  return switch_stream(c, c->own_stream);
 }
 int ecgpu_synchronize(ecgpu_ctx* c) {
   if (!c) return ECGPU_ERR_ARG;
@@ -243,6 +259,48 @@ int ecgpu_synchronize(ecgpu_ctx* c) {
   return ECGPU_OK;
 }
 const char* ecgpu_last_error(const ecgpu_ctx* c) { return c ? c->err : "null context"; }
+int ecgpu_last_error_copy(ecgpu_ctx* c, char* buf, size_t cap) {
+  if (!c || !buf || cap == 0) return ECGPU_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->err_mu);
+  strncpy(buf, c->err, cap - 1);
+  buf[cap - 1] = 0;
+  return ECGPU_OK;
+}
+
+int ecgpu_set_option(ecgpu_ctx* c, int option, int64_t v) {
+  if (!c) return ECGPU_ERR_ARG;
+  bool ok = false;
+  switch (option) {
+    case ECGPU_OPT_FB_WINDOW: ok = (v == 0 || v == 8 || v == 16 || v == 20 || v == 24 || v == 26); break;
+    case ECGPU_OPT_FB_MAX_WINDOW: ok = (v == 8 || v == 16 || v == 20 || v == 24 || v == 26); break;
+    case ECGPU_OPT_MSM_WINDOW_BITS: ok = (v == 0 || v == 16 || v == 19); break;
+    case ECGPU_OPT_MSM_SLAB_TERMS: ok = (v == 0 || (v >= 1024 && v <= ((int64_t)1 << 24))); break;
+    case ECGPU_OPT_MSM_SMALL_PATH: ok = (v == 0 || v == 1); break;
+    case ECGPU_OPT_MSM_ROUNDS: ok = (v >= 0 && v <= 64); break;
+    case ECGPU_OPT_K256_WAVES: ok = (v == 3 || v == 4); break;
+    case ECGPU_OPT_FB_MEMORY_BUDGET: ok = (v >= 0); break;
+    default: return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_set_option: unknown option %d", option);
+  }
+  if (!ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_set_option: value %lld is not allowed for option %d", (long long)v, option);
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->opt[option] = v;
+  return ECGPU_OK;
+}
+int ecgpu_get_option(ecgpu_ctx* c, int option, int64_t* v) {
+  if (!c || !v) return ECGPU_ERR_ARG;
+  if (option < 0 || option >= ECGPU_OPT_COUNT_) return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_get_option: unknown option %d", option);
+  std::lock_guard<std::mutex> lk(c->mu);
+  *v = c->opt[option];
+  return ECGPU_OK;
+}
+int ecgpu_fb_table_bytes(ecgpu_ctx* c, int curve, size_t* bytes, int* widest) {
+  if (!c) return ECGPU_ERR_ARG;
+  if (curve < 0 || curve > 2) return ecgpu_set_err(c, ECGPU_ERR_UNSUPPORTED, "curve %d not supported", curve);
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (bytes) *bytes = c->fb_bytes[curve];
+  if (widest) *widest = c->fb_widest[curve];
+  return ECGPU_OK;
+}
 
 int ecgpu_host_alloc(ecgpu_ctx* c, size_t bytes, void** out) {
   if (!c || !out) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
@@ -347,11 +405,25 @@ int ecgpu_batch_normalize(ecgpu_ctx* c, int curve, const uint8_t* p, uint8_t* ou
   return finish_host(c, mem);
 }
 
-// clear a staging slot that held secret scalars (ordered after the kernels that read it)
-static int wipe_stage(ecgpu_ctx* c, int slot) {
-  if (c->stage[slot] && c->stage_cap[slot]) HIPCHK(c, hipMemsetAsync(c->stage[slot], 0, c->stage_cap[slot], c->stream));
-  return 0;
-}
+// Staged copies of secret scalars do not outlive the call (the reference zeroizes its secrets): the guard clears the
+// bytes this call staged in its slots on EVERY exit path, the error returns included, and waits for the clearing.
+struct SecretWipe {
+  ecgpu_ctx* c;
+  int slot[4];
+  size_t bytes[4];
+  int cnt = 0;
+  explicit SecretWipe(ecgpu_ctx* ctx) : c(ctx) {}
+  void arm(int s, size_t b) { if (cnt < 4) { slot[cnt] = s; bytes[cnt] = b; cnt++; } }
+  ~SecretWipe() {
+    if (!cnt) return;
+    for (int i = 0; i < cnt; i++) {
+      const size_t b = bytes[i] < c->stage_cap[slot[i]] ? bytes[i] : c->stage_cap[slot[i]];
+      if (c->stage[slot[i]] && b) (void)hipMemsetAsync(c->stage[slot[i]], 0, b, c->stream);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
+  }
+};
 
 static int lincomb_impl(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t terms, uint8_t* out, int out_fmt,
                         uint8_t* out_inf, uint8_t* scalar_ok, size_t n, int mem, unsigned flags) {
@@ -364,7 +436,9 @@ static int lincomb_impl(ecgpu_ctx* c, int curve, const uint8_t* scalars, const u
   const size_t pin = (pt_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb, pout = (out_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb;
   // the reference schedule is the one meant for secret scalars: their staged copies do not outlive the call
   const bool secret = (flags & (ECGPU_EXACT_REFERENCE | ECGPU_SECRET_SCALARS)) != 0;
+  SecretWipe wipe(c);
   if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
+    if (secret) for (int sl = 0; sl < 2; sl++) wipe.arm(6 + sl * PIPE_MAXARGS, PIPE_CHUNK * terms * nb);
     const PipeArg args[5] = {{scalars, nullptr, terms * nb}, {points, nullptr, points ? terms * pin : 0}, {nullptr, out, pout},
                              {nullptr, out_fmt == ECGPU_PT_AFFINE ? out_inf : nullptr, 1}, {nullptr, scalar_ok, 1}};
     int rc = host_pipeline(c, args, 5, n, [&](void** d, size_t cnt) {
@@ -374,14 +448,11 @@ static int lincomb_impl(ecgpu_ctx* c, int curve, const uint8_t* scalars, const u
       }
       return ops->lincomb(c, (const uint32_t*)d[0], (const uint32_t*)d[1], pt_fmt, terms, (uint32_t*)d[2], out_fmt, (uint8_t*)d[3], cnt, flags);
     });
-    if (secret) {
-      for (int sl = 0; sl < 2; sl++) { int r2 = wipe_stage(c, 6 + sl * PIPE_MAXARGS); if (r2 && !rc) rc = r2; }
-      (void)hipStreamSynchronize(c->stream);
-    }
     return rc;
   }
   Buf bs, bp, bo, bi, bk;
   int rc;
+  if (secret && mem == ECGPU_MEM_HOST) wipe.arm(0, n * terms * nb);
   if ((rc = buf_in(c, bs, 0, scalars, n * terms * nb, mem))) return rc;
   if ((rc = buf_in(c, bp, 1, points, n * terms * pin, mem))) return rc;
   if ((rc = buf_out(c, bo, 2, out, n * pout, mem))) return rc;
@@ -394,7 +465,6 @@ static int lincomb_impl(ecgpu_ctx* c, int curve, const uint8_t* scalars, const u
   if ((rc = buf_finish(c, bo))) return rc;
   if ((rc = buf_finish(c, bi))) return rc;
   if ((rc = buf_finish(c, bk))) return rc;
-  if (secret && mem == ECGPU_MEM_HOST && (rc = wipe_stage(c, 0))) return rc;
   return finish_host(c, mem);
 }
 
@@ -514,6 +584,37 @@ int ecgpu_from_bytes_batch(ecgpu_ctx* c, int curve, const uint8_t* in, uint8_t* 
   return finish_host(c, mem);
 }
 
+int ecgpu_sec1_encode_batch(ecgpu_ctx* c, int curve, const uint8_t* points, int pt_fmt, int compress, uint8_t* out, size_t n, int mem) {
+  if (!c || !points || !out) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (pt_fmt != ECGPU_PT_AFFINE && pt_fmt != ECGPU_PT_PROJECTIVE) return ecgpu_set_err(c, ECGPU_ERR_ARG, "bad point format");
+  if (n == 0) return ECGPU_OK;
+  ENTER(c, curve);
+  const size_t rec = 1 + (compress ? 1 : 2) * nb;
+  Buf bp, bo;
+  int rc;
+  if ((rc = buf_in(c, bp, 0, points, n * (pt_fmt == ECGPU_PT_PROJECTIVE ? 3 : 2) * nb, mem))) return rc;
+  if ((rc = buf_out(c, bo, 2, out, n * rec, mem))) return rc;
+  if ((rc = ops->sec1_encode(c, (const uint32_t*)bp.dev, pt_fmt, compress ? 1 : 0, (uint8_t*)bo.dev, n))) return rc;
+  if ((rc = buf_finish(c, bo))) return rc;
+  return finish_host(c, mem);
+}
+int ecgpu_sec1_decode_batch(ecgpu_ctx* c, int curve, const uint8_t* in, size_t record_bytes, uint8_t* out_xy, uint8_t* ok, size_t n, int mem) {
+  if (!c || !in || !out_xy || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (n == 0) return ECGPU_OK;
+  ENTER(c, curve);
+  if (record_bytes != 1 + nb && record_bytes != 1 + 2 * nb)
+    return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_sec1_decode_batch: record_bytes must be %zu (compressed) or %zu (uncompressed)", 1 + nb, 1 + 2 * nb);
+  Buf bi, bo, bk;
+  int rc;
+  if ((rc = buf_in(c, bi, 0, in, n * record_bytes, mem))) return rc;
+  if ((rc = buf_out(c, bo, 2, out_xy, n * 2 * nb, mem))) return rc;
+  if ((rc = buf_out(c, bk, 3, ok, n, mem))) return rc;
+  if ((rc = ops->sec1_decode(c, (const uint8_t*)bi.dev, record_bytes, (uint32_t*)bo.dev, (uint8_t*)bk.dev, n))) return rc;
+  if ((rc = buf_finish(c, bo))) return rc;
+  if ((rc = buf_finish(c, bk))) return rc;
+  return finish_host(c, mem);
+}
+
 // ---------------------------------------------------------------------------------------------
 int ecgpu_ecdsa_verify_batch(ecgpu_ctx* c, int curve, const uint8_t* prehash, const uint8_t* sig_rs, const uint8_t* pubkeys_xy, uint8_t* ok,
                              size_t n, int mem, unsigned flags) {
@@ -602,21 +703,21 @@ int ecgpu_ecdsa_sign_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, con
   if (!c || !secret_d || !nonce_k || !prehash || !sig_rs || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
   if (n == 0) return ECGPU_OK;
   ENTER(c, curve);
+  SecretWipe wipe(c);                        // staged secret keys and nonces are cleared on every exit path
   if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
+    for (int sl = 0; sl < 2; sl++)
+      for (int a = 0; a < 2; a++) wipe.arm(6 + sl * PIPE_MAXARGS + a, PIPE_CHUNK * nb);
     const PipeArg args[6] = {{secret_d, nullptr, nb}, {nonce_k, nullptr, nb}, {prehash, nullptr, nb}, {nullptr, sig_rs, 2 * nb},
                              {nullptr, recovery_id, 1}, {nullptr, ok, 1}};
     int prc = host_pipeline(c, args, 6, n, [&](void** d, size_t cnt) {
       return ops->ecdsa_sign(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (const uint32_t*)d[2], (uint32_t*)d[3], (uint8_t*)d[4], (uint8_t*)d[5], cnt,
                              flags);
     });
-    // the staged copies of the secret keys and nonces do not outlive the call (the reference zeroizes them)
-    for (int sl = 0; sl < 2; sl++)
-      for (int a = 0; a < 2; a++) { int r2 = wipe_stage(c, 6 + sl * PIPE_MAXARGS + a); if (r2 && !prc) prc = r2; }
-    (void)hipStreamSynchronize(c->stream);
     return prc;
   }
   Buf bd, bk, bz, bs, br, bo;
   int rc;
+  if (mem == ECGPU_MEM_HOST) { wipe.arm(0, n * nb); wipe.arm(1, n * nb); }
   if ((rc = buf_in(c, bd, 0, secret_d, n * nb, mem))) return rc;
   if ((rc = buf_in(c, bk, 1, nonce_k, n * nb, mem))) return rc;
   if ((rc = buf_in(c, bz, 4, prehash, n * nb, mem))) return rc;
@@ -629,10 +730,6 @@ int ecgpu_ecdsa_sign_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, con
   if ((rc = buf_finish(c, bs))) return rc;
   if ((rc = buf_finish(c, br))) return rc;
   if ((rc = buf_finish(c, bo))) return rc;
-  if (mem == ECGPU_MEM_HOST) {               // staged secret keys and nonces are cleared (the reference zeroizes them)
-    if ((rc = wipe_stage(c, 0))) return rc;
-    if ((rc = wipe_stage(c, 1))) return rc;
-  }
   return finish_host(c, mem);
 }
 

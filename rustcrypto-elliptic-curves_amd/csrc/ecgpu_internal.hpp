@@ -13,12 +13,14 @@
 struct ecgpu_ctx {
   int device = -1;
   int num_cus = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;           // blocking stream: ordered with the legacy default stream like any ordinary stream
+  hipStream_t stream = nullptr;               // where launches go; nullptr is a legitimate value (the legacy default stream)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_switch = nullptr;            // orders work across ecgpu_set_stream
   char err[512] = {0};
   std::mutex mu;
+  std::mutex err_mu;                          // guards err[] (ecgpu_set_err / ecgpu_last_error_copy)
+  int64_t opt[ECGPU_OPT_COUNT_] = {0, 26, 0, 0, 1, 0, 4, 0};      // ecgpu_option defaults
   // grow-only device staging buffers for ECGPU_MEM_HOST calls
   static constexpr int NSTAGE = 18;          // 6 for whole-batch staging + 2 pipeline slots x 6 arguments
   void* stage[NSTAGE] = {};
@@ -34,7 +36,9 @@ struct ecgpu_ctx {
   void* fb20_table[3] = {nullptr, nullptr, nullptr};   // 20-bit-window variant for very large batches
   void* fbct_table[3] = {nullptr, nullptr, nullptr};   // 5-bit windows, read in full by the constant-time kernel (signing)
   void* fb24_table[3] = {nullptr, nullptr, nullptr};   // 24-bit windows (5.9 GB for a 256-bit curve): batches of 2^23 and more
-  void* fb26_table[3] = {nullptr, nullptr, nullptr};   // 26-bit windows (21 GB): on request only (ECGPU_FB_WINDOW=26)
+  void* fb26_table[3] = {nullptr, nullptr, nullptr};   // 26-bit windows (21.5 GB): batches of 2^24 and more on the 256-bit curves
+  size_t fb_bytes[3] = {0, 0, 0};                      // device memory held by the generator tables of a curve
+  int fb_widest[3] = {0, 0, 0};
   // per-lane table workspace of the k256 variable-base kernel (grow-only)
   void* tab_ws = nullptr;
   size_t tab_ws_cap = 0;
@@ -48,6 +52,7 @@ struct ecgpu_ctx {
 
 static inline int ecgpu_set_err(ecgpu_ctx* c, int code, const char* fmt, ...) {
   if (c) {
+    std::lock_guard<std::mutex> lk(c->err_mu);
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(c->err, sizeof(c->err), fmt, ap);
@@ -85,6 +90,8 @@ struct ecgpu_curve_ops {
   int (*synth_points)(ecgpu_ctx* c, uint64_t seed, uint64_t first, uint32_t* out_xy, size_t n);
   int (*to_bytes)(ecgpu_ctx* c, const uint32_t* pts, int pt_fmt, uint8_t* out, size_t n);
   int (*from_bytes)(ecgpu_ctx* c, const uint8_t* in, uint32_t* out_xy, uint8_t* ok, size_t n);
+  int (*sec1_encode)(ecgpu_ctx* c, const uint32_t* pts, int pt_fmt, int compress, uint8_t* out, size_t n);
+  int (*sec1_decode)(ecgpu_ctx* c, const uint8_t* in, size_t record_bytes, uint32_t* out_xy, uint8_t* ok, size_t n);
   int (*ecdsa_verify)(ecgpu_ctx* c, const uint32_t* z, const uint32_t* sig, const uint32_t* q_xy, uint8_t* ok, size_t n, unsigned flags);
   int (*h2c_map)(ecgpu_ctx* c, const uint32_t* u, int count, uint32_t* out_xy, uint8_t* out_inf, size_t n);
   int (*ecdsa_recover)(ecgpu_ctx* c, const uint32_t* z, const uint32_t* sig, const uint8_t* recid, uint32_t* out_xy, uint8_t* ok, size_t n,

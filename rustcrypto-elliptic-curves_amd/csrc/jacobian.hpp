@@ -17,6 +17,18 @@ struct AffEntry {   // affine table entry in the curve's internal field form (no
   typename C::Fe x, y;
 };
 
+// Where a lane keeps the recoded digits of the unit it is working on.  The window loops read ONE word of them per window,
+// indexed by the (wave-uniform) loop counter; kept in registers that is NW VGPRs held across every field operation of
+// the loop plus an NW-way select chain per read.  On the device the kernels hand in a column of a __shared__ array
+// (word q of lane t at base[q * 256 + t]: consecutive lanes hit consecutive banks, conflict-free) - 160 KB of LDS per CU
+// over 1 024 resident lanes is 40 dwords per lane, enough for the digits of one unit; the host twin passes a plain array.
+struct DigitMem {
+  u32* base;
+  int stride;
+  ECGPU_HD void st(int q, u32 v) const { base[q * stride] = v; }
+  ECGPU_HD u32 ld(int q) const { return base[q * stride]; }
+};
+
 namespace jac {
 
 template <class C> ECGPU_HD void set_infinity(Jac<C>& p) { C::fe_zero(p.x); C::fe_zero(p.y); C::fe_zero(p.z); }

@@ -331,10 +331,11 @@ __device__ __forceinline__ void k256_fast_rescale(TabSlotK256* tab, const FeK256
 #pragma unroll 1
   for (int j = 0; j < 8; j++) {
     FeK256 y;
-    k256::mul(tab[2 * j].x, tab[2 * j].x, s2);
-    k256::mul(tab[2 * j + 1].x, tab[2 * j + 1].x, s2);
-    k256::mul(y, tab[2 * j].y, s3);
-    tab[2 * j].y = y; tab[2 * j + 1].y = y;
+    constexpr int SS = K256_SLOT_STRIDE;
+    k256::mul(tab[SS * j].x, tab[SS * j].x, s2);
+    k256::mul(y, tab[SS * j].y, s3);
+    tab[SS * j].y = y;
+    if constexpr (SS == 2) { k256::mul(tab[2 * j + 1].x, tab[2 * j + 1].x, s2); tab[2 * j + 1].y = y; }
   }
 }
 

@@ -1043,13 +1043,12 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
   const size_t nb = (size_t)NWIN * G::NBUCKET;
   // Large sums run in slabs of at most SLAB_TERMS terms (a sorted entry keeps the term index in INDEX_BITS bits); every
   // slab goes through the whole pipeline down to its NWIN window sums, which are added up before the final Horner pass.
-  // ECGPU_MSM_SLAB overrides the slab size (tests exercise the slab loop on small inputs).
-  const char* slab_env = getenv("ECGPU_MSM_SLAB");
-  size_t slab = slab_env ? (size_t)atoll(slab_env) : G::SLAB_TERMS;
+  // ECGPU_OPT_MSM_SLAB_TERMS overrides the slab size (tests exercise the slab loop on small inputs).
+  size_t slab = c->opt[ECGPU_OPT_MSM_SLAB_TERMS] ? (size_t)c->opt[ECGPU_OPT_MSM_SLAB_TERMS] : G::SLAB_TERMS;
   if (slab < 1024 || slab > G::SLAB_TERMS) slab = G::SLAB_TERMS;
   const size_t m = n < slab ? n : slab;                // terms of the largest slab: sizes the workspace
   // bucket-sum runs: `rounds` per lane the chip holds at that kernel's occupancy (4 workgroups of 256 per CU)
-  static const int rounds = [] { const char* e = getenv("ECGPU_MSM_ROUNDS"); int v = e ? atoi(e) : MSM_ROUNDS; return (v < 1 || v > 64) ? MSM_ROUNDS : v; }();
+  const int rounds = (c->opt[ECGPU_OPT_MSM_ROUNDS] >= 1 && c->opt[ECGPU_OPT_MSM_ROUNDS] <= 64) ? (int)c->opt[ECGPU_OPT_MSM_ROUNDS] : MSM_ROUNDS;
   const u32 ntask = (u32)rounds * (u32)c->num_cus * 1024u;
   const size_t sz_aff = (pt_fmt == FMT_PROJECTIVE) ? al(m * 8 * NW) : 0, sz_prep = al((size_t)NHALF * m * 8 * NW);
   const size_t sz_off = al((nb + 1) * 4), sz_coff = al((size_t)(NCB + 1) * 4), sz_tot = al((size_t)NCB * 4), sz_sorted = al((size_t)NDIG * m * 4 + 32);
@@ -1164,8 +1163,8 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
 }
 
 // `mul` is the curve's batch scalar multiplication (used for small sums).
-// ECGPU_MSM_SMALL = 0 forces the bucket method for every size, ECGPU_MSM_CBITS = 16 | 19 one window width (both read per
-// call so that one process can exercise every path: measurements, tests of the bucket paths on small inputs).
+// ECGPU_OPT_MSM_SMALL_PATH = 0 forces the bucket method for every size, ECGPU_OPT_MSM_WINDOW_BITS = 16 | 19 one window width
+// (per-context options, include/ecgpu.h: measurements, tests of the bucket paths on small inputs).
 // 19-bit windows pay between these sizes (tools/msm_sizes.sh; ms at 16 / 19 bits - k256: 2^20 2.72 / 2.84, 2^21 3.96 / 3.90,
 // 2^22 6.34 / 6.17, 2^23 10.96 / 10.2, 2^24 20.06 / 20.17; p256: 2^21 4.98 / 5.51, 2^22 7.94 / 7.73, 2^23 12.93 / 12.33,
 // 2^24 22.96 / 23.48; p384: 2^21 18.1 / 19.1, 2^22 28.8 / 28.4): below, the eight times larger bucket tree costs more than
@@ -1178,10 +1177,14 @@ template <class C, class MulFn>
 static int msm_run(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt, MulFn mul) {
   constexpr int NW = C::NW;
   using J = Jac<C>;
-  if (((uintptr_t)pts & 15) || ((uintptr_t)sc & 3)) return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_msm: device points must be 16-byte aligned");
-  const char* small_env = getenv("ECGPU_MSM_SMALL");
-  const bool small_path = !(small_env && atoi(small_env) == 0);
-  if (small_path && n > 0 && n < SMALL_MSM_TERMS) {
+  if ((uintptr_t)sc & 3) return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_msm: the scalars must be 4-byte aligned");
+  if ((uintptr_t)pts & 3) return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_msm: the points must be 4-byte aligned");
+  const bool small_path = c->opt[ECGPU_OPT_MSM_SMALL_PATH] != 0;
+  const bool small = small_path && n > 0 && n < SMALL_MSM_TERMS;
+  // the bucket path reads AFFINE input points with 16-byte loads (projective input is normalised into the workspace first)
+  if (!small && pt_fmt == FMT_AFFINE && ((uintptr_t)pts & 15))
+    return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_msm: affine device points must be 16-byte aligned for sums of %zu terms and more", (size_t)SMALL_MSM_TERMS);
+  if (small) {
     // n scalar multiplications on the throughput kernel, then a two-level sum of the products
     auto al = msm_align;
     const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
@@ -1199,8 +1202,7 @@ static int msm_run(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size
     HIPCHK(c, hipGetLastError());
     return 0;
   }
-  const char* cb_env = getenv("ECGPU_MSM_CBITS");
-  const int cb = cb_env ? atoi(cb_env) : 0;
+  const int cb = (int)c->opt[ECGPU_OPT_MSM_WINDOW_BITS];
   const bool wide = (cb == 19) || (cb != 16 && n >= wide_window_min<C>() && n < WIDE_WINDOW_MAX);
   return wide ? msm_buckets<C, 19>(c, sc, pts, pt_fmt, n, out, out_fmt) : msm_buckets<C, 16>(c, sc, pts, pt_fmt, n, out, out_fmt);
 }

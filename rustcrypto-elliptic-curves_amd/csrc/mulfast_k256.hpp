@@ -29,7 +29,15 @@ struct JacK256 {   // x = X / Z^2, y = Y / Z^3, infinity <=> Z == 0
 struct alignas(16) TabSlotK256 {
   FeK256 x, y;
 };
+// ECGPU_K256_NO_BETA_SLOTS (A/B switch): 8 slots of (x, y) only, 512 B per lane; the lambda half multiplies x by beta when it
+// reads an entry (one more multiplication on half of the additions) instead of keeping beta*x beside x (1 KB per lane).
+#ifdef ECGPU_K256_NO_BETA_SLOTS
+constexpr int K256_TAB_SLOTS = 8;
+constexpr int K256_SLOT_STRIDE = 1;
+#else
 constexpr int K256_TAB_SLOTS = 16;
+constexpr int K256_SLOT_STRIDE = 2;
+#endif
 
 namespace k256 {
 
@@ -112,8 +120,9 @@ ECGPU_HD void table_build_globalz(TabSlotK256* tab, FeK256& zglobal, const FeK25
   FeK256 beta_; beta(beta_);
   // scale m[j] to the denominator of m[7]: s_j = Z7 / Z_j = prod_{i > j} zr[i]
   FeK256 s; set_one(s);
-  tab[14].x = m[7].x; tab[14].y = m[7].y; tab[15].y = m[7].y;
-  mul(tab[15].x, m[7].x, beta_);
+  constexpr int SS = K256_SLOT_STRIDE;
+  tab[7 * SS].x = m[7].x; tab[7 * SS].y = m[7].y;
+  if constexpr (SS == 2) { tab[15].y = m[7].y; mul(tab[15].x, m[7].x, beta_); }
 #pragma unroll 1
   for (int j = 6; j >= 0; j--) {
     if (j >= 1) mul(s, s, zr[j + 1]);        // s = Z7 / Z_j for j >= 1 (Z_1 = Z(m[1]))
@@ -124,8 +133,8 @@ ECGPU_HD void table_build_globalz(TabSlotK256* tab, FeK256& zglobal, const FeK25
     FeK256 tx, ty;
     mul(tx, m[j].x, s2);
     mul(ty, m[j].y, s3);
-    tab[2 * j].x = tx; tab[2 * j].y = ty; tab[2 * j + 1].y = ty;
-    mul(tab[2 * j + 1].x, tx, beta_);
+    tab[SS * j].x = tx; tab[SS * j].y = ty;
+    if constexpr (SS == 2) { tab[2 * j + 1].y = ty; mul(tab[2 * j + 1].x, tx, beta_); }
   }
 }
 
@@ -133,10 +142,18 @@ ECGPU_HD void table_build_globalz(TabSlotK256* tab, FeK256& zglobal, const FeK25
 ECGPU_HD void add_digit(JacK256& acc, const TabSlotK256* tab, int d, bool lam, bool neg) {
   const int ad = d < 0 ? -d : d;
   if (ad != 0) {
+#ifdef ECGPU_K256_NO_BETA_SLOTS
+    const TabSlotK256* e = tab + (ad - 1);
+    ECGPU_TABLE_TOUCH(ad - 1);
+    FeK256 x = e->x;
+    FeK256 y = e->y;
+    if (lam) { FeK256 b; beta(b); mul(x, x, b); }
+#else
     const TabSlotK256* e = tab + (2 * (ad - 1) + (lam ? 1 : 0));
     ECGPU_TABLE_TOUCH(2 * (ad - 1) + (lam ? 1 : 0));
     FeK256 x = e->x;
     FeK256 y = e->y;
+#endif
     if (neg != (d < 0)) k256::neg(y, y);
     jac_add_mixed(acc, x, y, nullptr);
   }

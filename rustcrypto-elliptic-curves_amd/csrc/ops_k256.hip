@@ -11,8 +11,8 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
   if (terms == 1 && !pts) return mul_gen_fast(c, sc, out, out_fmt, out_inf, n);
   if (terms != 1 && terms != 2) return 0;
   if (!pts) return 0;
-  // ECGPU_K256_FAST_WAVES (2/3/4) picks the occupancy variant; default chosen from measurements (profiles/r01_kbench_variants.txt)
-  static const int waves = [] { const char* e = getenv("ECGPU_K256_FAST_WAVES"); int w = e ? atoi(e) : 4; return (w < 3 || w > 4) ? 4 : w; }();
+  // ECGPU_OPT_K256_WAVES (3 / 4) picks the occupancy variant; default chosen from measurements (profiles/r01_kbench_variants.txt)
+  const int waves = c->opt[ECGPU_OPT_K256_WAVES] == 3 ? 3 : 4;
   const unsigned grid = ecgpu_grid_for(c, n, terms == 2 ? 4 : waves);
   // per-lane table workspace: 1 KB per resident lane (268 MB at 4 waves/SIMD on 256 CUs), grow-only
   const size_t ws_need = (size_t)grid * 256 * K256_TAB_SLOTS * sizeof(TabSlotK256) * terms;
@@ -34,6 +34,9 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
   HIPCHK(c, hipGetLastError());
   return 1;
 }
+// secret scalars on a variable base: the reference schedule (GLV + complete formulas, masked scans) is the constant-time one here
+template <>
+int CurveOps<CurveK256>::mul_ct(ecgpu_ctx*, const u32*, const u32*, int, u32*, int, uint8_t*, size_t) { return 0; }
 // Pippenger MSM (msm.hpp, msm_kernels.hpp; instantiated in msm_k256.hip)
 static int k256_mul_for_msm(ecgpu_ctx* c, const u32* s, const u32* p, int fmt, u32* prod, size_t cnt) {
   return CurveOps<CurveK256>::lincomb(c, s, p, fmt, 1, prod, FMT_AFFINE, nullptr, cnt, 0);

@@ -40,7 +40,7 @@ struct LaneWs {
 // 267-multiplication chain, the extra pass over the tables cost P-256 more than the cheaper additions saved).
 template <class C, int BATCH, int NT = 1, int AFFINE = -1>
 ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf, size_t n, size_t base,
-                        size_t T, LaneWs<C, BATCH>& ws) {
+                        size_t T, LaneWs<C, BATCH>& ws, const DigitMem& dm) {
   static_assert(BATCH % NT == 0 && BATCH <= 32, "table slots per pass");
   constexpr int NW = C::NW;
   constexpr int UB = BATCH / NT;               // units per pass
@@ -141,7 +141,11 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
   for (int b = 0; b < cnt; b++) {
     const size_t i = base + (size_t)b * T;
     // signed nibbles: digit_j = nibble_j(k + 0x88..8) - 8, the carry out of the top nibble is the last digit
-    u32 y[NT][NW], carry[NT];
+    // (the recoded words go to DigitMem - LDS on the device - instead of NT * NW registers held across the whole loop)
+    u32 carry[NT];
+#ifdef ECGPU_DIGITS_IN_REGISTERS                 // A/B switch: the round-2 form (NT * NW VGPRs and a select chain per read)
+    u32 y[NT][NW];
+#endif
 #pragma unroll
     for (int tt = 0; tt < NT; tt++) {
       const int s = b * NT + tt;
@@ -151,14 +155,17 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
       reduce_once<NW>(k, ord);
       if ((flips >> s) & 1u) { mp_sub<NW>(t, ord, k); mp_copy<NW>(k, t); }
       u32 c = 0;
+      const bool skip = (infs >> s) & 1u;       // an identity input contributes nothing: all its digits read as zero
 #pragma unroll
-      for (int w = 0; w < NW; w++) y[tt][w] = addc(k[w], 0x88888888u, c);
-      if ((infs >> s) & 1u) {                   // an identity input contributes nothing: all its digits read as zero
-        c = 0;
-#pragma unroll
-        for (int w = 0; w < NW; w++) y[tt][w] = 0x88888888u;
+      for (int w = 0; w < NW; w++) {
+        const u32 yw = addc(k[w], 0x88888888u, c);
+#ifdef ECGPU_DIGITS_IN_REGISTERS
+        y[tt][w] = skip ? 0x88888888u : yw;
+#else
+        dm.st(tt * NW + w, skip ? 0x88888888u : yw);
+#endif
       }
-      carry[tt] = c;
+      carry[tt] = skip ? 0u : c;
     }
     Jac<C> acc;
     jac::set_infinity<C>(acc);
@@ -176,11 +183,15 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
 #pragma unroll
           for (int q = 0; q < NT; q++) sd = (q == tt) ? (int)carry[q] : sd;
         } else {
+#ifdef ECGPU_DIGITS_IN_REGISTERS
           u32 word = y[0][0];
 #pragma unroll
           for (int r = 0; r < NT; r++)
 #pragma unroll
             for (int q = 0; q < NW; q++) word = (r == tt && (j >> 3) == q) ? y[r][q] : word;
+#else
+          const u32 word = dm.ld(tt * NW + (j >> 3));
+#endif
           sd = (int)((word >> (4 * (j & 7))) & 15u) - 8;
         }
         if (sd != 0) {

@@ -33,6 +33,8 @@ K256, P256, P384 = 0, 1, 2
 CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384}
 FIELD_BYTES = {K256: 32, P256: 32, P384: 48}
 FE_MUL, FE_SQR, FE_ADD, FE_SUB, FE_NEG, FE_INV, FE_SQRT = range(7)
+# ecgpu_option (per-context tuning / test knobs, include/ecgpu.h)
+OPT_FB_WINDOW, OPT_FB_MAX_WINDOW, OPT_MSM_WINDOW_BITS, OPT_MSM_SLAB_TERMS, OPT_MSM_SMALL_PATH, OPT_MSM_ROUNDS, OPT_K256_WAVES, OPT_FB_MEMORY_BUDGET = range(8)
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # ECGPU_LIB: another build of the library (A/B measurements of compile-time switches); default: the in-tree build
@@ -60,6 +62,13 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.ecgpu_destroy.argtypes = [vp]
     lib.ecgpu_destroy.restype = None
     lib.ecgpu_set_stream.argtypes = [vp, vp]
+    lib.ecgpu_use_own_stream.argtypes = [vp]
+    lib.ecgpu_last_error_copy.argtypes = [vp, ctypes.c_char_p, sz]
+    lib.ecgpu_set_option.argtypes = [vp, i, ctypes.c_int64]
+    lib.ecgpu_get_option.argtypes = [vp, i, ctypes.POINTER(ctypes.c_int64)]
+    lib.ecgpu_fb_table_bytes.argtypes = [vp, i, ctypes.POINTER(sz), ctypes.POINTER(i)]
+    lib.ecgpu_sec1_encode_batch.argtypes = [vp, i, u8p, i, i, u8p, sz, i]
+    lib.ecgpu_sec1_decode_batch.argtypes = [vp, i, u8p, sz, u8p, u8p, sz, i]
     lib.ecgpu_synchronize.argtypes = [vp]
     lib.ecgpu_last_error.argtypes = [vp]
     lib.ecgpu_last_error.restype = ctypes.c_char_p
@@ -100,7 +109,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
                  "ecgpu_synth_scalars", "ecgpu_synth_points", "ecgpu_point_eq_batch", "ecgpu_mul_batch_checked",
                  "ecgpu_lincomb_batch_checked", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_sign_batch", "ecgpu_to_bytes_batch",
                  "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch",
-                 "ecgpu_ecdsa_recover_batch", "ecgpu_map_to_curve_batch"):
+                 "ecgpu_ecdsa_recover_batch", "ecgpu_map_to_curve_batch", "ecgpu_use_own_stream", "ecgpu_last_error_copy",
+                 "ecgpu_set_option", "ecgpu_get_option", "ecgpu_fb_table_bytes", "ecgpu_sec1_encode_batch", "ecgpu_sec1_decode_batch"):
         getattr(lib, name).restype = ctypes.c_int
     if path is None:
         _lib = lib
@@ -115,6 +125,8 @@ EXPORTED_SYMBOLS = (
     "ecgpu_synth_scalars", "ecgpu_synth_points", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_sign_batch",
     "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch", "ecgpu_ecdsa_recover_batch", "ecgpu_map_to_curve_batch",
     "ecgpu_point_eq_batch", "ecgpu_mul_batch_checked", "ecgpu_lincomb_batch_checked",
+    "ecgpu_use_own_stream", "ecgpu_last_error_copy", "ecgpu_set_option", "ecgpu_get_option", "ecgpu_fb_table_bytes",
+    "ecgpu_sec1_encode_batch", "ecgpu_sec1_decode_batch",
 )
 
 
@@ -166,7 +178,32 @@ class Context:
             raise EcgpuError(f"ecgpu error {rc}: {self.lib.ecgpu_last_error(self.handle).decode()}")
 
     def set_stream(self, stream_handle: int):
-        self.check(self.lib.ecgpu_set_stream(self.handle, ctypes.c_void_p(stream_handle)))
+        """All later launches go to this hipStream_t; 0 / None is the legacy default stream (PyTorch's default stream)."""
+        self.check(self.lib.ecgpu_set_stream(self.handle, ctypes.c_void_p(stream_handle or None)))
+
+    def use_own_stream(self):
+        """Back to the context's own (blocking) stream."""
+        self.check(self.lib.ecgpu_use_own_stream(self.handle))
+
+    def set_option(self, option: int, value: int):
+        self.check(self.lib.ecgpu_set_option(self.handle, option, value))
+
+    def get_option(self, option: int) -> int:
+        v = ctypes.c_int64()
+        self.check(self.lib.ecgpu_get_option(self.handle, option, ctypes.byref(v)))
+        return v.value
+
+    def fb_table_bytes(self, curve) -> tuple:
+        """(bytes of device memory held by the curve's generator tables, widest window among them)"""
+        cid = CURVE_IDS[curve] if isinstance(curve, str) else int(curve)
+        b, w = ctypes.c_size_t(), ctypes.c_int()
+        self.check(self.lib.ecgpu_fb_table_bytes(self.handle, cid, ctypes.byref(b), ctypes.byref(w)))
+        return b.value, w.value
+
+    def last_error(self) -> str:
+        buf = ctypes.create_string_buffer(512)
+        self.lib.ecgpu_last_error_copy(self.handle, buf, 512)
+        return buf.value.decode()
 
     def synchronize(self):
         self.check(self.lib.ecgpu_synchronize(self.handle))
@@ -310,8 +347,9 @@ class Curve:
     def diffie_hellman(self, secret_scalars, public_keys_xy) -> np.ndarray:
         """elliptic_curve::ecdh::diffie_hellman for a batch: SharedSecret = x((public * secret).to_affine())
         (k256/src/ecdh.rs:41-45).  Inputs are what the reference's types guarantee: non-zero scalars, valid keys.
-        The scalars are secret: the multiplication runs on the constant-time reference schedule."""
-        out, _ = self.mul(secret_scalars, public_keys_xy, flags=EXACT_REFERENCE)
+        The scalars are secret: ECGPU_SECRET_SCALARS selects the constant-time variable-base kernel (csrc/varbase_ct.hpp) on
+        P-256 / P-384 and the reference schedule, constant-time as well, on secp256k1."""
+        out, _ = self.mul(secret_scalars, public_keys_xy, flags=SECRET_SCALARS)
         return np.ascontiguousarray(out[:, :self.nb])
 
     def _check_device(self, t, need_bytes: int, what: str):
@@ -376,6 +414,20 @@ class Curve:
         e = _as_host(encoded, self.nb + 1)
         out, ok = _host_out(len(e), 2 * self.nb), np.zeros(len(e), dtype=np.uint8)
         self.ctx.check(self.ctx.lib.ecgpu_from_bytes_batch(self.ctx.handle, self.id, _ptr(e)[0], _ptr(out)[0], _ptr(ok)[0], len(e), HOST))
+        return out, ok
+
+    # --- ToEncodedPoint::to_encoded_point / FromEncodedPoint::from_encoded_point (fixed-width records) -------------
+    def sec1_encode(self, points, compress: bool = False, point_format: int = AFFINE) -> np.ndarray:
+        p = _as_host(points, (3 if point_format == PROJECTIVE else 2) * self.nb)
+        out = _host_out(len(p), 1 + (1 if compress else 2) * self.nb)
+        self.ctx.check(self.ctx.lib.ecgpu_sec1_encode_batch(self.ctx.handle, self.id, _ptr(p)[0], point_format, int(bool(compress)), _ptr(out)[0], len(p), HOST))
+        return out
+
+    def sec1_decode(self, encoded, record_bytes: Optional[int] = None):
+        rb = record_bytes or (1 + 2 * self.nb)
+        e = _as_host(encoded, rb)
+        out, ok = _host_out(len(e), 2 * self.nb), np.zeros(len(e), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ecgpu_sec1_decode_batch(self.ctx.handle, self.id, _ptr(e)[0], rb, _ptr(out)[0], _ptr(ok)[0], len(e), HOST))
         return out, ok
 
     # --- ECDSA: VerifyPrimitive::verify_prehashed / SignPrimitive::try_sign_prehashed ------------------

@@ -38,16 +38,32 @@ pub const ECGPU_EXACT_REFERENCE: c_uint = 1;
 pub const ECGPU_ECDSA_LOW_S: c_uint = 2;
 /// signing only: the nonces are public, k G may use the throughput fixed-base schedule
 pub const ECGPU_PUBLIC_SCALARS: c_uint = 4;
-/// secret scalars, group element only: constant-time fixed base for k G (key generation), the reference schedule for a variable base
+/// secret scalars, group element only: constant-time fixed base for k G (key generation); for a variable base (ECDH) the
+/// constant-time kernel of csrc/varbase_ct.hpp on P-256 / P-384 and the reference schedule on secp256k1
 pub const ECGPU_SECRET_SCALARS: c_uint = 8;
+/// `ecgpu_option`: per-context tuning / test knobs (the library never reads the process environment)
+pub const ECGPU_OPT_FB_WINDOW: c_int = 0;
+pub const ECGPU_OPT_FB_MAX_WINDOW: c_int = 1;
+pub const ECGPU_OPT_MSM_WINDOW_BITS: c_int = 2;
+pub const ECGPU_OPT_MSM_SLAB_TERMS: c_int = 3;
+pub const ECGPU_OPT_MSM_SMALL_PATH: c_int = 4;
+pub const ECGPU_OPT_MSM_ROUNDS: c_int = 5;
+pub const ECGPU_OPT_K256_WAVES: c_int = 6;
+pub const ECGPU_OPT_FB_MEMORY_BUDGET: c_int = 7;
+pub const ECGPU_OPT_COUNT_: c_int = 8;
 
 #[link(name = "ecgpu")]
 extern "C" {
     pub fn ecgpu_create(ctx: *mut *mut ecgpu_ctx, device_index: c_int) -> c_int;
     pub fn ecgpu_destroy(ctx: *mut ecgpu_ctx);
     pub fn ecgpu_set_stream(ctx: *mut ecgpu_ctx, hip_stream: *mut c_void) -> c_int;
+    pub fn ecgpu_use_own_stream(ctx: *mut ecgpu_ctx) -> c_int;
     pub fn ecgpu_synchronize(ctx: *mut ecgpu_ctx) -> c_int;
     pub fn ecgpu_last_error(ctx: *const ecgpu_ctx) -> *const c_char;
+    pub fn ecgpu_last_error_copy(ctx: *mut ecgpu_ctx, buf: *mut c_char, cap: usize) -> c_int;
+    pub fn ecgpu_set_option(ctx: *mut ecgpu_ctx, option: c_int, value: i64) -> c_int;
+    pub fn ecgpu_get_option(ctx: *mut ecgpu_ctx, option: c_int, value: *mut i64) -> c_int;
+    pub fn ecgpu_fb_table_bytes(ctx: *mut ecgpu_ctx, curve: c_int, bytes: *mut usize, widest_window: *mut c_int) -> c_int;
     pub fn ecgpu_version() -> *const c_char;
     pub fn ecgpu_field_bytes(curve: c_int) -> usize;
     pub fn ecgpu_host_alloc(ctx: *mut ecgpu_ctx, bytes: usize, out: *mut *mut c_void) -> c_int;
@@ -75,6 +91,10 @@ extern "C" {
     pub fn ecgpu_decompress_batch(ctx: *mut ecgpu_ctx, curve: c_int, x: *const u8, y_is_odd: *const u8, out_xy: *mut u8, ok: *mut u8, n: usize, mem: c_int) -> c_int;
     pub fn ecgpu_to_bytes_batch(ctx: *mut ecgpu_ctx, curve: c_int, points: *const u8, point_format: c_int, out: *mut u8, n: usize, mem: c_int) -> c_int;
     pub fn ecgpu_from_bytes_batch(ctx: *mut ecgpu_ctx, curve: c_int, input: *const u8, out_xy: *mut u8, ok: *mut u8, n: usize, mem: c_int) -> c_int;
+    pub fn ecgpu_sec1_encode_batch(ctx: *mut ecgpu_ctx, curve: c_int, points: *const u8, point_format: c_int, compress: c_int, out: *mut u8, n: usize,
+                                   mem: c_int) -> c_int;
+    pub fn ecgpu_sec1_decode_batch(ctx: *mut ecgpu_ctx, curve: c_int, input: *const u8, record_bytes: usize, out_xy: *mut u8, ok: *mut u8, n: usize,
+                                   mem: c_int) -> c_int;
     pub fn ecgpu_ecdsa_verify_batch(ctx: *mut ecgpu_ctx, curve: c_int, prehash: *const u8, sig_rs: *const u8, pubkeys_xy: *const u8, ok: *mut u8, n: usize,
                                     mem: c_int, flags: c_uint) -> c_int;
     pub fn ecgpu_ecdsa_sign_batch(ctx: *mut ecgpu_ctx, curve: c_int, secret_d: *const u8, nonce_k: *const u8, prehash: *const u8, sig_rs: *mut u8,
@@ -99,7 +119,10 @@ pub struct Error {
 /// callers use the raw functions with `ECGPU_MEM_DEVICE`.
 pub struct Context(*mut ecgpu_ctx);
 
-// the library serialises calls on one context with its own lock (ecgpu.h: "Re-entrant; one context per device")
+// The library serialises calls on one context with its own lock (ecgpu.h: "Re-entrant; one context per device"), and
+// `check` reads the error text through ecgpu_last_error_copy, which takes the lock the writers of that buffer take: a
+// `&Context` may be used from several threads.  (The text is the context's LAST error: with concurrent failing calls a
+// thread may read its neighbour's message; the status code it got back is always its own.)
 unsafe impl Send for Context {}
 unsafe impl Sync for Context {}
 
@@ -118,7 +141,9 @@ impl Context {
     pub fn raw(&self) -> *mut ecgpu_ctx { self.0 }
     fn check(&self, rc: c_int) -> Result<(), Error> {
         if rc == ECGPU_OK { return Ok(()); }
-        let msg = unsafe { std::ffi::CStr::from_ptr(ecgpu_last_error(self.0)) }.to_string_lossy().into_owned();
+        let mut buf = [0 as c_char; 512];
+        unsafe { ecgpu_last_error_copy(self.0, buf.as_mut_ptr(), buf.len()) };
+        let msg = unsafe { std::ffi::CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned();
         Err(Error { code: rc, message: msg })
     }
     pub fn field_bytes(curve: c_int) -> usize { unsafe { ecgpu_field_bytes(curve) } }
@@ -298,5 +323,26 @@ impl Context {
         self.check(unsafe { ecgpu_map_to_curve_batch(self.0, curve, u.as_ptr(), count, xy.as_mut_ptr(), inf.as_mut_ptr(), n, ECGPU_MEM_HOST) })?;
         Ok((xy, inf))
     }
+    /// ToEncodedPoint::to_encoded_point(compress) in fixed-width records (identity: tag 0x00 and zero padding)
+    pub fn sec1_encode(&self, curve: c_int, points: &[u8], point_format: c_int, compress: bool) -> Result<Vec<u8>, Error> {
+        let nb = Self::field_bytes(curve);
+        let w = Self::pt_bytes(nb, point_format);
+        Self::arg(nb != 0 && points.len() % w == 0)?;
+        let n = points.len() / w;
+        let mut out = vec![0u8; n * (1 + if compress { nb } else { 2 * nb })];
+        self.check(unsafe { ecgpu_sec1_encode_batch(self.0, curve, points.as_ptr(), point_format, compress as c_int, out.as_mut_ptr(), n, ECGPU_MEM_HOST) })?;
+        Ok(out)
+    }
+    /// FromEncodedPoint::from_encoded_point on records of 1 + NB or 1 + 2 NB bytes -> (x || y, ok flags)
+    pub fn sec1_decode(&self, curve: c_int, encoded: &[u8], record_bytes: usize) -> Result<(Vec<u8>, Vec<u8>), Error> {
+        let nb = Self::field_bytes(curve);
+        Self::arg(nb != 0 && (record_bytes == 1 + nb || record_bytes == 1 + 2 * nb) && encoded.len() % record_bytes == 0)?;
+        let n = encoded.len() / record_bytes;
+        let (mut xy, mut ok) = (vec![0u8; 2 * nb * n], vec![0u8; n]);
+        self.check(unsafe { ecgpu_sec1_decode_batch(self.0, curve, encoded.as_ptr(), record_bytes, xy.as_mut_ptr(), ok.as_mut_ptr(), n, ECGPU_MEM_HOST) })?;
+        Ok((xy, ok))
+    }
+    pub fn set_option(&self, option: c_int, value: i64) -> Result<(), Error> { self.check(unsafe { ecgpu_set_option(self.0, option, value) }) }
+    pub fn use_own_stream(&self) -> Result<(), Error> { self.check(unsafe { ecgpu_use_own_stream(self.0) }) }
     pub fn synchronize(&self) -> Result<(), Error> { self.check(unsafe { ecgpu_synchronize(self.0) }) }
 }

@@ -104,9 +104,11 @@ template <class C, int NT>
 static int vb_walk(const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, size_t lanes) {
   constexpr int BATCH = 8;
   vb::LaneWs<C, BATCH>* ws = (vb::LaneWs<C, BATCH>*)malloc(sizeof(vb::LaneWs<C, BATCH>));
+  u32 digits[NT * C::NW];
+  const DigitMem dm{digits, 1};
   for (size_t tid = 0; tid < lanes; tid++)
     for (size_t base = tid; base < n; base += lanes * (BATCH / NT))
-      vb::lane_pass<C, BATCH, NT>((const u32*)scalars, (const u32*)points, pt_fmt, (u32*)out, out_fmt, out_inf, n, base, lanes, *ws);
+      vb::lane_pass<C, BATCH, NT>((const u32*)scalars, (const u32*)points, pt_fmt, (u32*)out, out_fmt, out_inf, n, base, lanes, *ws, dm);
   free(ws);
   return 0;
 }
@@ -122,6 +124,31 @@ extern "C" int ht_vb_lincomb(int curve, const uint8_t* scalars, const uint8_t* p
 extern "C" int ht_vb_mul(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
                          size_t lanes) {
   return ht_vb_lincomb(curve, scalars, points, pt_fmt, 1, out, out_fmt, out_inf, n, lanes);
+}
+
+// ---- constant-time variable base (varbase_ct.hpp): the per-lane body walked as `lanes` lanes over a lane-interleaved
+//      workspace of stride `lanes`, exactly as the kernel lays it out with stride 256.  The trace hook records the table
+//      entries the window loop reads.
+#include "varbase_ct.hpp"
+template <class C>
+static int vbct_walk(const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, size_t lanes) {
+  constexpr int BATCH = 8;
+  vbct::Chunk* mem = (vbct::Chunk*)aligned_alloc(16, sizeof(vbct::Chunk) * vbct::lane_chunks<C, BATCH>() * lanes);
+  memset(mem, 0xA5, sizeof(vbct::Chunk) * vbct::lane_chunks<C, BATCH>() * lanes);
+  u32 digits[C::NW];
+  const DigitMem dm{digits, 1};
+  for (size_t tid = 0; tid < lanes; tid++) {
+    const vbct::LaneMem ws{mem + tid, lanes};
+    for (size_t base = tid; base < n; base += lanes * BATCH)
+      vbct::lane_pass<C, BATCH>((const u32*)scalars, (const u32*)points, pt_fmt, (u32*)out, out_fmt, out_inf, n, base, lanes, ws, dm);
+  }
+  free(mem);
+  return 0;
+}
+extern "C" int ht_vbct_mul(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
+                           size_t lanes) {
+  return curve == 1 ? vbct_walk<CurveP256>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes)
+                    : vbct_walk<CurveP384>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
 }
 
 // ---- XYZZ bucket accumulator of the MSM (msm.hpp) over any curve: p (X||Y||ZZ||ZZZ) += q (affine x||y), converted to the

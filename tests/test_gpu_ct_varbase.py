@@ -1,0 +1,129 @@
+"""Constant-time variable base for secret scalars (ECGPU_SECRET_SCALARS with a point: ECDH), csrc/varbase_ct.hpp.
+
+P-256 / P-384 run `vbct::mul_kernel` (Jacobian doublings, masked scans of per-lane affine tables, exception-free by the
+fold k -> min(k, n - k)); secp256k1 has no dedicated kernel and takes the reference schedule (GLV + complete formulas),
+which is constant-time as well.  Every curve is compared with the C oracle at 2^20 units:
+with 262 144 resident lanes that is 4 table slots per lane, so the shared table inversion and the batched output run
+over several units; a second, ragged case adds a second pass.  Planted: zero, one, n - 1, the scalars a windowed
+Jacobian schedule without the fold would break on (n - 2, n - 6, n - 16 .. n - 1), (n +- 1) / 2, scalars >= n, identity
+points, and the same point with k and n - k.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import coracle as CO
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+THREADS = max(1, min(os.cpu_count() or 1, 16))
+ORDER = {0: synth.M.K256.n, 1: synth.M.P256.n, 2: synth.M.P384.n}
+
+
+def _edge_values(n_ord, nb):
+    return ([0, 1, 2, 8, 9, 16, (n_ord - 1) // 2, (n_ord + 1) // 2, n_ord + 3, (1 << (8 * nb)) - 1, int("8" * (2 * nb), 16) % n_ord]
+            + [n_ord - d for d in range(1, 18)])
+
+
+def _run(cname, cid, n, first, sample_all):
+    import torch
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cname)
+    nb = cv.nb
+    lanes = 4 * torch.cuda.get_device_properties(0).multi_processor_count * 256
+    d_s = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
+    d_p = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+    d_o = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+    d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_s, n, synth.SEED, first)
+    cv.synth_points_device(d_p, n, synth.SEED, first)
+    ctx.synchronize()
+    vals = _edge_values(ORDER[cid], nb)
+    planted = {}
+    # spread the edge scalars over the slots of a lane (index = slot * lanes + lane) and both passes
+    for j, v in enumerate(vals):
+        i = (j % 8) * lanes + 1000 + 7 * j
+        if i >= n:
+            i = (j * 7919 + 13) % n
+        planted[i] = v
+    for i, v in planted.items():
+        d_s[i] = torch.from_numpy(np.frombuffer(int(v).to_bytes(nb, "big"), dtype=np.uint8).copy()).cuda()
+    ident = [5, lanes + 77, n - 3]
+    for i in ident:
+        d_p[i] = 0
+    torch.cuda.synchronize()
+    cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i, flags=ecgpu.SECRET_SCALARS)
+    ctx.synchronize()
+    if sample_all:
+        idx = np.arange(n)
+    else:
+        idx = np.unique(np.concatenate([np.arange(0, 4096), np.arange(n - 4096, n), np.arange(0, n, max(1, n // 32768)),
+                                        np.array(sorted(planted) + ident, dtype=np.int64)]))
+    t_idx = torch.from_numpy(idx).cuda()
+    s = d_s[t_idx].cpu().numpy()
+    p = d_p[t_idx].cpu().numpy()
+    got = torch.cat([d_o[t_idx], d_i[t_idx, None]], dim=1).cpu().numpy()
+    sw = s.copy()
+    for i, v in planted.items():                  # the oracle takes canonical scalars
+        if v >= ORDER[cid]:
+            sw[np.searchsorted(idx, i)] = np.frombuffer(int(v % ORDER[cid]).to_bytes(nb, "big"), dtype=np.uint8)
+    want = CO.lincomb_batch(cid, sw, p, threads=THREADS)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "units %s differ from the oracle" % idx[bad[:8]].tolist()
+    for i in ident:
+        r = got[np.searchsorted(idx, i)]
+        assert r[-1] == 1 and not r[:-1].any(), i
+    # the public-data throughput schedule must give the same bytes
+    d_o2 = torch.empty_like(d_o)
+    d_i2 = torch.empty_like(d_i)
+    cv.mul_device(d_s, d_p, d_o2, n, d_out_inf=d_i2)
+    ctx.synchronize()
+    assert torch.equal(d_o, d_o2) and torch.equal(d_i, d_i2)
+    ctx.close()
+
+
+@pytest.mark.parametrize("cname,cid", [("p256", 1), ("p384", 2), ("k256", 0)])
+def test_secret_scalar_variable_base_2p20(cname, cid):
+    _run(cname, cid, 1 << 20, 70_000_000 + cid, sample_all=True)
+
+
+@pytest.mark.parametrize("cname,cid", [("p256", 1), ("p384", 2)])
+def test_secret_scalar_variable_base_two_passes(cname, cid):
+    """2^21 + 2^18 + 777 units: a full pass of 8 slots per lane and a ragged second pass."""
+    _run(cname, cid, (1 << 21) + (1 << 18) + 777, 80_000_000 + cid, sample_all=False)
+
+
+@pytest.mark.parametrize("cname,cid", [("p256", 1), ("p384", 2), ("k256", 0)])
+def test_ecdh_uses_the_secret_scalar_schedule(cname, cid):
+    """Curve.diffie_hellman (elliptic_curve::ecdh::diffie_hellman, k256/src/ecdh.rs:41-45): both sides agree, the shared
+    secret is x(k P) of the model, projective input and output work, and the reference schedule gives the same bytes."""
+    import ecgpu
+    c = synth.M.CURVES[cname]
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cname)
+    nb = cv.nb
+    n = 300
+    a = [synth.scalar(c, 9000 + i) or 1 for i in range(n)]
+    b = [synth.scalar(c, 9500 + i) or 1 for i in range(n)]
+    a[0], b[1], a[2] = 1, c.n - 1, c.n - 2
+    tob = lambda v: int(v).to_bytes(nb, "big")
+    pa, _ = cv.mul_by_generator(b"".join(map(tob, a)), flags=ecgpu.SECRET_SCALARS)
+    pb, _ = cv.mul_by_generator(b"".join(map(tob, b)), flags=ecgpu.SECRET_SCALARS)
+    s1 = cv.diffie_hellman(b"".join(map(tob, a)), pb)
+    s2 = cv.diffie_hellman(b"".join(map(tob, b)), pa)
+    assert bytes(s1) == bytes(s2)
+    for i in (0, 1, 2, 17, n - 1):
+        want = synth.M.affine_mul(c, a[i] * b[i] % c.n, (c.gx, c.gy))
+        assert bytes(s1[i]) == synth.M.i2b(c, want[0]), i
+    ref, _ = cv.mul(b"".join(map(tob, a)), pb, flags=ecgpu.EXACT_REFERENCE)
+    assert bytes(ref[:, :nb]) == bytes(s1)
+    proj = cv.mul(b"".join(map(tob, a)), pb, out_format=ecgpu.PROJECTIVE, flags=ecgpu.SECRET_SCALARS)
+    if cid == 0:          # secp256k1: the reference schedule, hence the reference's own (X, Y, Z)
+        xy, _ = cv.batch_normalize(proj)
+        assert bytes(xy[:, :nb]) == bytes(s1)
+    else:                 # (x : y : 1)
+        one = (1).to_bytes(nb, "big")
+        assert all(bytes(proj[i][:nb]) == bytes(s1[i]) and bytes(proj[i][2 * nb:]) == one for i in range(n))
+    ctx.close()

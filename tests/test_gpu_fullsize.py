@@ -46,7 +46,6 @@ def _run_varbase(cname, cid, n, first, edges):
     d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
     cv.synth_scalars_device(d_s, n, synth.SEED, first)
     cv.synth_points_device(d_p, n, synth.SEED, first)
-    ctx.synchronize()          # torch's default stream has handle 0 = "the context's own stream": not ordered with torch's work
     order = {0: synth.M.K256.n, 1: synth.M.P256.n, 2: synth.M.P384.n}[cid]
     planted = []
     for slot, pass_, lane, kind in edges(lanes):

@@ -13,27 +13,25 @@ C = M.K256
 N = C.n
 
 
-def _set_path(path):
+def _set_path(ctx, path, slab=0):
     """"auto": the library's own choice (below 5 * 2^14 terms: n scalar multiplications and a tree sum; 16-bit windows
     below 2^21 terms, 19-bit windows from there on); "buckets16" / "buckets19": the bucket method with that window width
-    forced for all sizes (ECGPU_MSM_SMALL=0, ECGPU_MSM_CBITS: both read per call)."""
-    import os
-    os.environ.pop("ECGPU_MSM_SMALL", None)
-    os.environ.pop("ECGPU_MSM_CBITS", None)
-    if path != "auto":
-        os.environ["ECGPU_MSM_SMALL"] = "0"
-        os.environ["ECGPU_MSM_CBITS"] = path[-2:]
+    forced for all sizes (per-context options ECGPU_OPT_MSM_SMALL_PATH = 0 and ECGPU_OPT_MSM_WINDOW_BITS); slab: terms per
+    slab of the bucket method (0: the window's maximum)."""
+    import ecgpu
+    ctx.set_option(ecgpu.OPT_MSM_SMALL_PATH, 1 if path == "auto" else 0)
+    ctx.set_option(ecgpu.OPT_MSM_WINDOW_BITS, 0 if path == "auto" else int(path[-2:]))
+    ctx.set_option(ecgpu.OPT_MSM_SLAB_TERMS, slab)
 
 
 @pytest.fixture(scope="module", params=["auto", "buckets16", "buckets19"])
 def curve(request):
     """Every test runs three times: see _set_path."""
     import ecgpu
-    _set_path(request.param)
     ctx = ecgpu.Context(0)
+    _set_path(ctx, request.param)
     yield ctx.curve("k256")
     ctx.close()
-    _set_path("auto")
 
 
 def arr(rows, w):
@@ -174,26 +172,20 @@ def test_oversized_sort_bins(curve):
 
 def test_slabs_of_a_large_sum():
     """Sums above 2^24 terms run in slabs whose window sums are added (a sorted entry keeps the term index in 24 bits).
-    ECGPU_MSM_SLAB shrinks the slab so that the loop - three slabs, the last one ragged - runs on 2^16 + 777 terms."""
-    import os
+    ECGPU_OPT_MSM_SLAB_TERMS shrinks the slab so that the loop - three slabs, the last one ragged - runs on 2^16 + 777 terms."""
     import ecgpu
-    try:
-        ctx = ecgpu.Context(0)
-        cv = ctx.curve("k256")
-        n = (1 << 16) + 777
-        s = CO.synth_scalars(0, n, synth.SEED, 123)
-        p = CO.synth_points(0, n, synth.SEED, 123)
-        p[40000] = 0
-        s[50000] = 0
-        want = CO.msm_naive(0, s, p)
-        for path in ("buckets16", "buckets19"):
-            _set_path(path)
-            os.environ["ECGPU_MSM_SLAB"] = "30000"
-            assert bytes(cv.msm(s, p)) == bytes(want[:64]) and want[64] == 0, path
-        ctx.close()
-    finally:
-        _set_path("auto")
-        os.environ.pop("ECGPU_MSM_SLAB", None)
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve("k256")
+    n = (1 << 16) + 777
+    s = CO.synth_scalars(0, n, synth.SEED, 123)
+    p = CO.synth_points(0, n, synth.SEED, 123)
+    p[40000] = 0
+    s[50000] = 0
+    want = CO.msm_naive(0, s, p)
+    for path in ("buckets16", "buckets19"):
+        _set_path(ctx, path, slab=30000)
+        assert bytes(cv.msm(s, p)) == bytes(want[:64]) and want[64] == 0, path
+    ctx.close()
 
 
 def _oracle_sum(cid, c, s, p, threads=16):
@@ -215,14 +207,13 @@ def test_nist_msm(cn, cid, path):
     """The bucket method on the curves without an endomorphism (one half-term per term, 16 / 24 windows of 16 bits and a
     carry window, or 14 / 21 windows of 19 bits; sign fold k > n/2 -> n - k): edge cases against the big-integer model, 2^13 unstructured terms against the C oracle, and
     2^18 structured terms P_i = (a0 + i d) G against the closed form (sum k_i (a0 + i d) mod n) G."""
-    import os
     import torch
     import ecgpu
     c = M.CURVES[cn]
     nb, n_ord = c.nbytes, c.n
-    _set_path(path)
+    ctx = ecgpu.Context(0)
     try:
-        ctx = ecgpu.Context(0)
+        _set_path(ctx, path)
         cv = ctx.curve(cn)
         G = (c.gx, c.gy)
         rng = random.Random(64 + cid)
@@ -265,9 +256,8 @@ def test_nist_msm(cn, cid, path):
             tot = sum(int.from_bytes(kb[nb * i:nb * i + nb], "big") * vals[i] for i in range(n)) % n_ord
             w = M.affine_mul(c, tot, G)
             assert bytes(d_out.cpu().numpy()) == M.i2b(c, w[0]) + M.i2b(c, w[1])
-        ctx.close()
     finally:
-        _set_path("auto")
+        ctx.close()
 
 
 @pytest.mark.parametrize("cn,cid", [("k256", 0), ("p256", 1)])
@@ -275,7 +265,6 @@ def test_bucket_path_agrees_with_term_by_term_path_on_awkward_sizes(cn, cid):
     """Two independent routes to the same sum - the bucket method (digits, two-level sort, bucket parts, reduction tree)
     and n scalar multiplications folded by a tree - on sizes around the wave, workgroup, chunk-alignment (multiples of
     four) and slab boundaries, with duplicate points, identity points, zero scalars and repeated scalars mixed in."""
-    import os
     import ecgpu
     ctx = ecgpu.Context(0)
     cv = ctx.curve(cn)
@@ -291,17 +280,13 @@ def test_bucket_path_agrees_with_term_by_term_path_on_awkward_sizes(cn, cid):
     try:
         for n in (1, 2, 3, 5, 63, 64, 65, 255, 257, 1023, 1025, 4093, 4095, 4097, 32767, 65537, 131071, 131075):
             s, p = s_all[:n], p_all[:n]
-            _set_path("auto")
-            os.environ.pop("ECGPU_MSM_SLAB", None)
+            _set_path(ctx, "auto")
             a = bytes(cv.msm(s, p))
             for path in ("buckets16", "buckets19"):
-                _set_path(path)
-                os.environ.pop("ECGPU_MSM_SLAB", None)
+                _set_path(ctx, path)
                 assert bytes(cv.msm(s, p)) == a, (path, n)
                 if n > 5000:
-                    os.environ["ECGPU_MSM_SLAB"] = "4099"      # ragged slabs (not a multiple of four)
+                    _set_path(ctx, path, slab=4099)            # ragged slabs (not a multiple of four)
                     assert bytes(cv.msm(s, p)) == a, (path, "slabs", n)
     finally:
-        _set_path("auto")
-        os.environ.pop("ECGPU_MSM_SLAB", None)
         ctx.close()

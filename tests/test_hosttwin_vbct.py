@@ -1,0 +1,124 @@
+"""Host build of the constant-time variable-base body (csrc/varbase_ct.hpp: the kernel behind ECGPU_SECRET_SCALARS with a
+variable base, i.e. ECDH on P-256 / P-384), walked with a handful of lanes over a lane-interleaved workspace:
+
+* k P against the big-integer model for random and edge scalars - including every scalar for which a windowed
+  Jacobian schedule WITHOUT the fold k -> min(k, n - k) would meet P + P or P - P in its last addition (n - 2 for
+  P-256, n - 6 for P-384, and the whole range n - 16 .. n - 1), zero, identity inputs, scalars >= n;
+* the sequence of table entries the window loop reads is the same for every scalar (all eight entries of the unit's
+  table, 8 NW + 1 times), which is the host-side half of the constant-time evidence (the device half is
+  profiles/r03_ct_counters.txt: identical instruction counters for different scalar sets).
+"""
+import ctypes
+import random
+
+import pytest
+
+from oracle import ecmodel as M
+from oracle import synth
+from hosttwin_util import lib, buf, outbuf
+
+CURVES = [("p256", 1), ("p384", 2)]
+
+
+def _vbct(cid, c, ks, ps, lanes, out_fmt=0, proj_in=False):
+    nb = c.nbytes
+    n = len(ks)
+    sb = b"".join(int(k).to_bytes(nb, "big") for k in ks)
+    if proj_in:
+        pb = b"".join(M.proj_bytes(c, p) for p in ps)
+    else:
+        pb = b"".join(M.i2b(c, p[0]) + M.i2b(c, p[1]) if p is not None else bytes(2 * nb) for p in ps)
+    out = outbuf((3 if out_fmt else 2) * nb * n)
+    inf = outbuf(n)
+    L = lib()
+    L.ht_vbct_mul.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                              ctypes.c_size_t, ctypes.c_size_t]
+    assert L.ht_vbct_mul(cid, buf(sb), buf(pb), 1 if proj_in else 0, out, out_fmt, inf, n, lanes) == 0
+    return bytes(out), bytes(inf)
+
+
+def edge_scalars(c):
+    n = c.n
+    return ([0, 1, 2, 7, 8, 9, 15, 16, 17, 0x88, 0x87, 0x89, (n - 1) // 2, (n + 1) // 2, (n + 3) // 2, (n - 3) // 2, n, n + 5,
+             1 << (8 * c.nbytes - 1), (1 << (8 * c.nbytes)) - 1, int("8" * (2 * c.nbytes), 16) % n, int("7" * (2 * c.nbytes), 16) % n]
+            + [n - d for d in range(1, 18)])
+
+
+@pytest.mark.parametrize("cn,cid", CURVES)
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_vbct_edge_and_random_scalars(cn, cid, lanes):
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    ks = edge_scalars(c) + [synth.scalar(c, 4000 + i) for i in range(11)]
+    n = len(ks)
+    ps = [synth.point(c, 4100 + (i % 5)) for i in range(n)]
+    ps[3] = None                                  # identity inputs, one of them with an edge scalar
+    ps[n - 2] = None
+    out, inf = _vbct(cid, c, ks, ps, lanes)
+    for i in range(n):
+        want = None if ps[i] is None else M.affine_mul(c, ks[i] % c.n, ps[i])
+        got = out[2 * nb * i:2 * nb * (i + 1)]
+        if want is None:
+            assert got == bytes(2 * nb) and inf[i] == 1, (i, hex(ks[i]))
+        else:
+            assert got == M.i2b(c, want[0]) + M.i2b(c, want[1]) and inf[i] == 0, (i, hex(ks[i]))
+    # projective in / projective out: (x : y : 1), identity (0 : 1 : 0)
+    rng = random.Random(77 + cid)
+    pp = [M.IDENTITY if p is None else (lambda z: (p[0] * z % c.p, p[1] * z % c.p, z))(rng.randrange(1, c.p)) for p in ps]
+    outp, _ = _vbct(cid, c, ks, pp, lanes, out_fmt=1, proj_in=True)
+    for i in range(n):
+        want = None if ps[i] is None else M.affine_mul(c, ks[i] % c.n, ps[i])
+        got = outp[3 * nb * i:3 * nb * (i + 1)]
+        if want is None:
+            assert got == M.proj_bytes(c, M.IDENTITY), i
+        else:
+            assert got == M.i2b(c, want[0]) + M.i2b(c, want[1]) + M.i2b(c, 1), i
+
+
+@pytest.mark.parametrize("cn,cid", CURVES)
+@pytest.mark.parametrize("lanes,n", [(3, 53), (2, 1), (5, 40)])
+def test_vbct_slot_counts_and_passes(cn, cid, lanes, n):
+    """(3, 53): two full passes and a ragged third; (2, 1): a single unit; (5, 40): exactly one pass."""
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    ks = [synth.scalar(c, 5000 + i) for i in range(n)]
+    ps = [synth.point(c, 5000 + i) for i in range(n)]
+    if n > 30:
+        ks[lanes * 2] = 0
+        ks[min(lanes * 9, n - 1)] = c.n - 2
+        ps[lanes * 4 + 1] = None
+    out, inf = _vbct(cid, c, ks, ps, lanes)
+    for i in range(n):
+        want = None if ps[i] is None else M.affine_mul(c, ks[i] % c.n, ps[i])
+        got = out[2 * nb * i:2 * nb * (i + 1)]
+        if want is None:
+            assert got == bytes(2 * nb) and inf[i] == 1, i
+        else:
+            assert got == M.i2b(c, want[0]) + M.i2b(c, want[1]) and inf[i] == 0, i
+
+
+def _trace(fn):
+    L = lib()
+    L.ht_trace_stop.restype = ctypes.c_size_t
+    L.ht_trace_stop.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.ht_trace_start()
+    fn()
+    cap = 1 << 16
+    arr = (ctypes.c_int * cap)()
+    cnt = L.ht_trace_stop(arr, cap)
+    assert cnt <= cap
+    return list(arr[:cnt])
+
+
+@pytest.mark.parametrize("cn,cid", CURVES)
+def test_vbct_reads_the_whole_table_for_every_scalar(cn, cid):
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    P = synth.point(c, 6000)
+    traces = []
+    for k in [0, 1, c.n - 1, c.n - 2, c.n - 6, (c.n - 1) // 2, int("f" * (2 * nb), 16) % c.n, int("8" * (2 * nb), 16) % c.n,
+              synth.scalar(c, 6001), synth.scalar(c, 6002)]:
+        traces.append(_trace(lambda: _vbct(cid, c, [k], [P], 1)))
+    nwin = 2 * nb + 1                                   # 8 NW nibbles and the carry digit
+    assert all(t == traces[0] for t in traces)
+    assert traces[0] == list(range(8)) * nwin

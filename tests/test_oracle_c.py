@@ -80,6 +80,12 @@ def test_point_ops_lincomb2_msm(cn, cid):
     assert bytes(got) == b"".join(M.proj_bytes(c, M.point_add(c, p, q)) for p, q in zip(ps, qs))
     got = CO.point_op(cid, 1, pa)
     assert bytes(got) == b"".join(M.proj_bytes(c, M.point_double(c, p)) for p in ps)
+    # add_mixed (k256 projective.rs:164-221, primeorder point_arithmetic.rs:247-277); an identity among the affine operands
+    aff = [M.to_affine(c, q) for q in qs]
+    aff[3] = M.to_affine(c, M.IDENTITY)
+    qx = arr([M.i2b(c, a[0]) + M.i2b(c, a[1]) for a in aff], 2 * c.nbytes)
+    got = CO.point_op(cid, 2, pa, qx)
+    assert bytes(got) == b"".join(M.proj_bytes(c, M.point_add_mixed(c, p, a)) for p, a in zip(ps, aff))
     n = 6
     ks = [rng.randrange(c.n) for _ in range(2 * n)]
     pts = [synth.point(c, i, seed=8) for i in range(2 * n)]

@@ -42,6 +42,17 @@ for cname in ("k256", "p256", "p384"):
             ctx.synchronize()
             cv.mul_device(d_s, d_p, d_o, n, out_format=ecgpu.PROJECTIVE, flags=flags)         # variable base
             ctx.synchronize()
+    # ECDH: a secret scalar on a variable base (ECGPU_SECRET_SCALARS: vbct::mul_kernel on P-256 / P-384, the reference schedule
+    # on secp256k1), random points, the three scalar sets plus one more: n - 2 / n - 6, where a schedule without the fold breaks
+    d_q = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+    cv.synth_points_device(d_q, n, 0xEC5CA1A5, 0)
+    ctx.synchronize()
+    extra = np.tile(np.frombuffer((c.n - (2 if cname != "p384" else 6)).to_bytes(nb, "big"), dtype=np.uint8), (n, 1))
+    for s in sets + [extra]:
+        d_s = torch.from_numpy(np.ascontiguousarray(s)).cuda()
+        torch.cuda.synchronize()
+        cv.mul_device(d_s, d_q, d_o, n, flags=ecgpu.SECRET_SCALARS)
+        ctx.synchronize()
     # signing: the nonce k takes the three sets (default flags: the constant-time fixed-base kernel fb::mul_ct_kernel)
     d_d = torch.from_numpy(np.ascontiguousarray(sets[2])).cuda()
     d_z = torch.from_numpy(np.ascontiguousarray(sets[2][::-1])).cuda()

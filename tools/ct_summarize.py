@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fold the counter CSV of tools/ct_evidence.py: per kernel, the counters of its consecutive dispatches (scalar sets
-"all ones", "all sevens", random).  python tools/ct_summarize.py gpurun_out/ct > profiles/r02_ct_counters.txt"""
+"all ones", "all sevens", random).  python tools/ct_summarize.py gpurun_out/ct > profiles/r03_ct_counters.txt"""
 import csv
 import glob
 import os

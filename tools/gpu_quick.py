@@ -11,6 +11,8 @@ mode = sys.argv[3] if len(sys.argv) > 3 else "var"
 flags = ecgpu.EXACT_REFERENCE if (len(sys.argv) > 4 and sys.argv[4] == "ref") else 0
 n = 1 << lg
 ctx = ecgpu.Context(0); cv = ctx.curve(cn); nb = cv.nb
+from _opts import apply_env_options
+apply_env_options(ctx)        # ECGPU_MSM_CBITS, ECGPU_FB_WINDOW ... -> ecgpu_set_option
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 d_s = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
 d_p = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")

@@ -12,8 +12,8 @@ from oracle import ecmodel as M, synth
 
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 n = 1 << lg
-os.environ["ECGPU_MSM_SMALL"] = "0"
 ctx = ecgpu.Context(0)
+ctx.set_option(ecgpu.OPT_MSM_SMALL_PATH, 0)
 cv = ctx.curve("k256")
 c = M.K256
 d_p = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
@@ -31,7 +31,7 @@ for name, k in (("all ones (a plain sum of points)", 1), ("all n - 1", c.n - 1),
         ctx.synchronize()
         dt = time.perf_counter() - t0
     # check: k * (sum of points) computed as the sum with unit scalars (the term-by-term path), then one multiplication
-    os.environ.pop("ECGPU_MSM_SMALL")
+    ctx.set_option(ecgpu.OPT_MSM_SMALL_PATH, 1)
     ones = torch.zeros((n, 32), dtype=torch.uint8, device="cuda"); ones[:, 31] = 1
     parts = []
     for lo in range(0, n, 1 << 16):                      # chunks below the small-path threshold
@@ -44,7 +44,7 @@ for name, k in (("all ones (a plain sum of points)", 1), ("all n - 1", c.n - 1),
     tot = torch.empty((64,), dtype=torch.uint8, device="cuda")
     cv.msm_device(ones[:len(parts)], allp, len(parts), tot)
     ctx.synchronize()
-    os.environ["ECGPU_MSM_SMALL"] = "0"
+    ctx.set_option(ecgpu.OPT_MSM_SMALL_PATH, 0)
     want, _ = cv.mul(np.frombuffer(k.to_bytes(32, "big"), dtype=np.uint8).reshape(1, 32), tot.cpu().numpy().reshape(1, 64))
     ok = bytes(want[0]) == bytes(d_o.cpu().numpy())
     print(f"{name}: n=2^{lg} {dt*1e3:.1f} ms  correct={ok}", flush=True)

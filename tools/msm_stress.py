@@ -48,7 +48,7 @@ for case in range(cases):
     torch.cuda.synchronize()
     res = {}
     for path in ("term", "b16", "b19"):
-        os.environ.pop("ECGPU_MSM_SMALL", None); os.environ.pop("ECGPU_MSM_CBITS", None); os.environ.pop("ECGPU_MSM_SLAB", None)
+        ctx.set_option(ecgpu.OPT_MSM_SMALL_PATH, 1); ctx.set_option(ecgpu.OPT_MSM_WINDOW_BITS, 0); ctx.set_option(ecgpu.OPT_MSM_SLAB_TERMS, 0)
         out = torch.empty((2 * nb,), dtype=torch.uint8, device="cuda")
         if path == "term":
             step = 60000
@@ -61,18 +61,16 @@ for case in range(cases):
             allp = torch.stack(parts).contiguous()
             parallel.fold_points_device(cv, allp, len(parts), torch.empty_like(allp), out, torch.empty((1,), dtype=torch.uint8, device="cuda"))
         else:
-            os.environ["ECGPU_MSM_SMALL"] = "0"
-            os.environ["ECGPU_MSM_CBITS"] = path[1:]
+            ctx.set_option(ecgpu.OPT_MSM_SMALL_PATH, 0)
+            ctx.set_option(ecgpu.OPT_MSM_WINDOW_BITS, int(path[1:]))
             if case % 5 == 0 and n > 3000:
-                os.environ["ECGPU_MSM_SLAB"] = str(int(rng.integers(1024, max(1025, n // 2))))
+                ctx.set_option(ecgpu.OPT_MSM_SLAB_TERMS, int(rng.integers(1024, max(1025, n // 2))))
             cv.msm_device(d_s, d_p, n, out)
         ctx.synchronize()
         res[path] = bytes(out.cpu().numpy())
     ok = res["term"] == res["b16"] == res["b19"]
     bad += 0 if ok else 1
     print("case %2d %s n=%6d mix=%d %s" % (case, cname, n, mix, "ok" if ok else "MISMATCH"), flush=True)
-for v in ("ECGPU_MSM_SMALL", "ECGPU_MSM_CBITS", "ECGPU_MSM_SLAB"):
-    os.environ.pop(v, None)
 ctx.close()
 print("mismatches: %d" % bad)
 sys.exit(1 if bad else 0)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fold the rocprofv3 outputs of tools/profile_headline.sh into one JSON summary (per-launch averages of
+"""Fold the rocprofv3 outputs of tools/profile_workload.sh into one JSON summary (per-launch averages of
 every counter for the kernels whose name contains MATCH, plus the kernel-trace average duration).
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reads
@@ -18,7 +18,9 @@ import sys
 
 def main():
     out, match = sys.argv[1], sys.argv[2]
-    known_read = float(sys.argv[3]) if len(sys.argv) > 3 else None
+    known_read = float(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] not in ("", "-") else None
+    workload = sys.argv[4] if len(sys.argv) > 4 else None
+    commit = sys.argv[5] if len(sys.argv) > 5 else None
     per = {}
     for path in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         acc = {}
@@ -38,7 +40,11 @@ def main():
             for row in csv.DictReader(f):
                 if match in row["Name"]:
                     dur = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "pct": float(row["Percentage"])}
-    res = {"kernel_match": match, "counters_per_launch": per, "kernel_trace": dur}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    # provenance: which workload of bench.py, the commit the tree was at (passed in: the GPU box has no .git) and the hash of
+    # the kernel sources that were profiled - bench.py recomputes the hash and says whether the sources have changed since
+    res = {"workload": workload, "commit": commit, "csrc_sha16": bench.csrc_sha16(), "kernel_match": match, "counters_per_launch": per, "kernel_trace": dur}
     if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
         raw = (per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
         x2 = (2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
