@@ -296,12 +296,15 @@ def measure_peak(device):
     return a.value, b.value
 
 
-def csrc_sha16():
-    """Hash of the kernel sources (csrc/*): ties a committed PMC summary to the code it was profiled on."""
+def csrc_sha16(workload=None):
+    """Hash of the kernel sources a workload runs (csrc/*; the MSM's own files count for the MSM only): ties a committed PMC
+    summary to the code it was profiled on."""
     import glob
     import hashlib
     h = hashlib.sha256()
     for path in sorted(glob.glob(os.path.join(ROOT, "rustcrypto-elliptic-curves_amd", "csrc", "*"))):
+        if os.path.basename(path).startswith("msm") and workload is not None and not WORKLOADS[workload]["msm"]:
+            continue
         if os.path.isfile(path):
             h.update(os.path.basename(path).encode())
             with open(path, "rb") as f:
@@ -527,7 +530,7 @@ def roofline_for(name, res, schedule, peak_meas, pair_meas, world=1):
     if pmc:
         kt = pmc.get("kernel_trace") or {}
         pmc_obj = {"source": pmc_file, "profiled_at_commit": pmc.get("commit"), "profiled_csrc_sha16": pmc.get("csrc_sha16"),
-                   "csrc_sha16_of_this_tree": csrc_sha16(), "kernel_sources_unchanged_since_profile": pmc.get("csrc_sha16") == csrc_sha16(),
+                   "csrc_sha16_of_this_tree": csrc_sha16(name), "kernel_sources_unchanged_since_profile": pmc.get("csrc_sha16") == csrc_sha16(name),
                    "kernel_match": pmc.get("kernel_match"), "profiled_kernel_ms": (kt.get("avg_ns") / 1e6 if kt.get("avg_ns") else None),
                    "hbm_bytes_per_launch": pmc.get("hbm_bytes_per_launch"), "traffic_over_algorithmic": (pmc["hbm_bytes_per_launch"] / (n * wl["bytes_per_unit"])
                                                                                                       if pmc.get("hbm_bytes_per_launch") else None),

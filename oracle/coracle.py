@@ -24,6 +24,7 @@ def lib():
         L.eco_point_op.argtypes = [i, i, vp, vp, vp, sz]
         L.eco_ecdsa_verify_batch.argtypes = [i, vp, vp, vp, vp, sz, i]
         L.eco_ecdsa_sign_batch.argtypes = [i, vp, vp, vp, vp, vp, vp, sz, i]
+        L.eco_p384_invert.argtypes = [i, vp, vp, sz]
         _LIB = L
     return _LIB
 
@@ -73,6 +74,15 @@ def point_op(curve, op, p, q=None):
     q = None if q is None else np.ascontiguousarray(q, dtype=np.uint8)
     out = np.zeros_like(p)
     assert lib().eco_point_op(curve, op, _p(p), _p(q), _p(out), p.shape[0]) == 0
+    return out
+
+
+def p384_invert(values, fermat=False):
+    """P-384 field inversion of (n, 48) canonical big-endian values: Bernstein-Yang divsteps as the reference
+    (p384 field.rs:67-91), or the Fermat chain kept for cross-checking."""
+    a = np.ascontiguousarray(values, dtype=np.uint8).reshape(-1, 48)
+    out = np.zeros_like(a)
+    assert lib().eco_p384_invert(1 if fermat else 0, _p(a), _p(out), a.shape[0]) == 0
     return out
 
 

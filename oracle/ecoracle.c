@@ -561,13 +561,86 @@ static void mfe_sqn_mul(const mcurve* c, mfe* acc, int k, const mfe* m) {
   while (k--) mfe_mul(c, acc, acc, acc);
   if (m) mfe_mul(c, acc, acc, m);
 }
-/* a^(p-2), the unique inverse, by a fixed addition chain.  P-256: the chain of p256 field.rs:357-382 (255 squarings +
- * 12 multiplications).  P-384: the reference inverts with Bernstein-Yang divsteps (p384 field.rs:67-91, ~1 100 divsteps on
- * 6-limb values, roughly the cost of 120-150 field multiplications); a port of fiat's divstep is out of proportion for one
- * call per scalar multiplication, so the oracle uses the Fermat chain for p - 2 = [255 ones][0][32 ones][64 zeros][30 ones]
- * [0][1] (385 squarings + 14 multiplications): the same field element, ~4 % more work per P-384 scalar multiplication
- * than the reference - the cpu_baseline for P-384 is that much pessimistic. */
+/* P-384 inversion as the reference does it: Bernstein-Yang divsteps (p384 field.rs:67-91 -> impl_bernstein_yang_invert,
+ * primeorder/src/field.rs:505-559).  (49 * 384 + 57) / 17 = 1 110 iterations of
+ *   divstep(delta, f, g, v, r):  if delta > 0 and g odd: (1 - delta, g, (g - f) / 2, 2 r, r - v)
+ *                                else:                    (1 + delta, f, (g + (g mod 2) f) / 2, 2 v, r + (g mod 2) v)
+ * (the postconditions of fiat_p384_divstep, p384_64.rs:3286-3313; f, g are 7-word two's-complement integers, v, r field
+ * elements), starting from f = m, g = from_montgomery(a), v = 0, r = 1; then v := -v if f < 0 and the result is
+ * v * precomp with precomp = ((m - 1) / 2)^1110 (fiat_p384_divstep_precomp), here computed once instead of tabulated.
+ * Branch-free like fiat's: every step runs the same additions under masks. */
+static mfe P384_BY_PRECOMP;
+static pthread_once_t p384_by_once = PTHREAD_ONCE_INIT;
+static void mfe_pow(const mcurve* c, mfe* r, const mfe* a, const u64* e);
+static void p384_by_init(void) {
+  const mcurve* c = &P384C;
+  u64 h[MAXL];                                           /* (m - 1) / 2 as an integer */
+  for (int i = 0; i < c->nl; i++) h[i] = (c->p[i] >> 1) | (i + 1 < c->nl ? c->p[i + 1] << 63 : 0);
+  mfe hm, t; memset(&hm, 0, sizeof(hm)); memset(&t, 0, sizeof(t));
+  memcpy(t.w, h, sizeof(u64) * c->nl);
+  mfe r2; memset(&r2, 0, sizeof(r2)); memcpy(r2.w, c->r2, sizeof(u64) * c->nl);
+  mfe_mul(c, &hm, &t, &r2);                              /* to Montgomery form */
+  u64 e[MAXL] = {1110, 0, 0, 0, 0, 0};
+  mfe_pow(c, &P384_BY_PRECOMP, &hm, e);
+}
+/* fixed-size helpers of the divstep loop (six-word field elements, seven-word integers) */
+static inline void by_addmod6(u64* r, const u64* a, const u64* b, const u64* p) {      /* (a + b) mod p for a < p, b <= p */
+  u64 t[7], d[6], carry = 0, bw = 0;
+  for (int i = 0; i < 6; i++) { u128 s = (u128)a[i] + b[i] + carry; t[i] = (u64)s; carry = (u64)(s >> 64); }
+  t[6] = carry;
+  for (int i = 0; i < 6; i++) { u128 s = (u128)t[i] - p[i] - bw; d[i] = (u64)s; bw = (u64)(s >> 64) & 1; }
+  const u64 m = 0 - (u64)((t[6] != 0) | (bw == 0));       /* t >= p */
+  for (int i = 0; i < 6; i++) r[i] = (d[i] & m) | (t[i] & ~m);
+}
+static void mfe_invert_by(const mcurve* c, mfe* out, const mfe* a) {
+  pthread_once(&p384_by_once, p384_by_init);
+  u64 f[7], g[7], v[6], r[6], P[6];
+  memcpy(P, c->p, sizeof(P));
+  memcpy(f, c->p, 48); f[6] = 0;                         /* msat: the modulus as a 7-word integer */
+  mfe one_plain; memset(&one_plain, 0, sizeof(one_plain)); one_plain.w[0] = 1;
+  mfe ac; mfe_mul(c, &ac, a, &one_plain);                /* from_montgomery */
+  memcpy(g, ac.w, 48); g[6] = 0;
+  memset(v, 0, sizeof(v)); memcpy(r, c->one, 48);
+  int64_t delta = 1;
+  for (int it = 0; it < 1110; it++) {
+    const u64 godd = 0 - (g[0] & 1);                      /* mask: g odd */
+    const u64 swap = godd & (0 - (u64)(delta > 0));       /* mask: delta > 0 and g odd */
+    /* t = g - f (swap) or g + (g odd ? f : 0); f' = swap ? g : f; g' = t >> 1 (arithmetic) */
+    u64 t[7], cy = swap & 1;
+    for (int i = 0; i < 7; i++) {
+      const u64 addend = (swap & ~f[i]) | (~swap & godd & f[i]);
+      u128 s2 = (u128)g[i] + addend + cy;
+      t[i] = (u64)s2; cy = (u64)(s2 >> 64);
+      f[i] = (swap & g[i]) | (~swap & f[i]);
+    }
+    for (int i = 0; i < 6; i++) g[i] = (t[i] >> 1) | (t[i + 1] << 63);
+    g[6] = (u64)((int64_t)t[6] >> 1);
+    /* v' = 2 (swap ? r : v);  r' = r + (g odd ? (swap ? -v : v) : 0)   (swap implies g odd) */
+    u64 sel[6], w[6], bw = 0;
+    for (int i = 0; i < 6; i++) { u128 d = (u128)P[i] - v[i] - bw; w[i] = (u64)d; bw = (u64)(d >> 64) & 1; }      /* p - v (= p for v = 0) */
+    for (int i = 0; i < 6; i++) {
+      sel[i] = (swap & r[i]) | (~swap & v[i]);
+      w[i] = godd & ((swap & w[i]) | (~swap & v[i]));
+    }
+    by_addmod6(r, r, w, P);
+    by_addmod6(v, sel, sel, P);
+    delta = (swap ? 1 - delta : 1 + delta);
+  }
+  const u64 neg = 0 - (f[6] >> 63);                       /* f < 0: the inverse is -v */
+  mfe vv, zero, nvv; memset(&zero, 0, sizeof(zero)); memset(&vv, 0, sizeof(vv)); memcpy(vv.w, v, 48);
+  mfe_sub(c, &nvv, &zero, &vv);
+  for (int i = 0; i < 6; i++) vv.w[i] = (neg & nvv.w[i]) | (~neg & vv.w[i]);
+  mfe_mul(c, out, &vv, &P384_BY_PRECOMP);
+}
+/* a^(p-2), the unique inverse.  P-256: the addition chain of p256 field.rs:357-382 (255 squarings + 12 multiplications).
+ * P-384: the Bernstein-Yang inversion above, as in the reference; the Fermat chain for p - 2 = [255 ones][0][32 ones]
+ * [64 zeros][30 ones][0][1] (385 squarings + 14 multiplications) stays for cross-checking (eco_p384_invert with which = 1). */
+static void mfe_invert_fermat(const mcurve* c, mfe* r, const mfe* a);
 static void mfe_invert(const mcurve* c, mfe* r, const mfe* a) {
+  if (c == &P384C) { mfe_invert_by(c, r, a); return; }
+  mfe_invert_fermat(c, r, a);
+}
+static void mfe_invert_fermat(const mcurve* c, mfe* r, const mfe* a) {
   if (c != &P256C && c != &P384C) {                 /* the scalar fields (ECDSA): plain a^(n-2) */
     u64 e[MAXL]; memcpy(e, c->p, sizeof(e)); e[0] -= 2;
     mfe_pow(c, r, a, e);
@@ -1073,6 +1146,19 @@ int eco_ecdsa_sign_batch(int curve, const u8* d, const u8* k, const u8* z, u8* s
     memcpy(o, R, nb); memcpy(o + nb, sb, nb);
     if (recid) recid[i] = (u8)(y_odd | (x_red << 1));
     ok[i] = 1;
+  }
+  return 0;
+}
+
+/* P-384 field inversion both ways (canonical big-endian in / out): which = 0 Bernstein-Yang (the reference's), 1 the Fermat chain */
+int eco_p384_invert(int which, const u8* a, u8* out, size_t n) {
+  const mcurve* c = get_mcurve(2);
+  if (!c) return -1;
+  for (size_t i = 0; i < n; i++) {
+    mfe x, r; memset(&x, 0, sizeof(x));
+    mfe_from_bytes(c, &x, a + 48 * i);
+    if (which == 0) mfe_invert_by(c, &r, &x); else mfe_invert_fermat(c, &r, &x);
+    mfe_to_bytes(c, out + 48 * i, &r);
   }
   return 0;
 }

@@ -258,11 +258,12 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
     u32 k[NW];
     const u32 flip = scalar_fold<C>(k, scalars + i * NW);
     u32 c = 0;
-#pragma unroll
 #ifdef ECGPU_DIGITS_IN_REGISTERS                 // A/B switch: NW VGPRs and a select chain per read
     u32 y[NW];
+#pragma unroll
     for (int w = 0; w < NW; w++) y[w] = addc(k[w], 0x88888888u, c);
 #else
+#pragma unroll
     for (int w = 0; w < NW; w++) dm.st(w, addc(k[w], 0x88888888u, c));       // the recoded digits leave the registers (DigitMem)
 #endif
     Jac<C> acc;

@@ -117,6 +117,7 @@ def test_k256_config2_2p24_second_pass():
     ("k256", 0, 1 << 23, 5),                       # BASELINE config 4, one GPU's share: 19-bit windows, one slab
     ("k256", 0, (1 << 24) + 777, 1 << 30),         # 16-bit windows, two slabs (24-bit term index), the second one tiny
     ("p256", 1, 1 << 22, 9),                       # 19-bit windows without the endomorphism (14 windows)
+    ("k256", 0, 1 << 26, 1 << 33),                 # BASELINE config 4's TOTAL size on one card: four slabs of the 16-bit path
 ])
 def test_msm_full_sizes_structured(cname, cid, n, first):
     """The MSM at sizes no term-by-term oracle reaches: P_i = (a0 + i d) G (computed on the device by the fixed-base path),
@@ -131,7 +132,11 @@ def test_msm_full_sizes_structured(cname, cid, n, first):
     cv = ctx.curve(cname)
     ps = bench.structured_point_scalars(first, n)
     d_pts = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
-    cv.mul_device(torch.from_numpy(ps).cuda(), None, d_pts, n)
+    d_ps = torch.from_numpy(ps).cuda()
+    del ps
+    cv.mul_device(d_ps, None, d_pts, n)
+    ctx.synchronize()
+    del d_ps
     d_s = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
     cv.synth_scalars_device(d_s, n, synth.SEED, first)
     ctx.synchronize()

@@ -99,3 +99,18 @@ def test_point_ops_lincomb2_msm(cn, cid):
     for k, P in zip(ks, pts):
         tot = M.affine_add(c, tot, M.affine_mul(c, k, P))
     assert bytes(CO.msm_naive(cid, sb, pb)) == M.affine_bytes(c, (tot[0], tot[1], 0))
+
+
+def test_p384_bernstein_yang_inversion_matches_fermat_and_model():
+    """oracle/ecoracle.c inverts in the P-384 base field the way the reference does (Bernstein-Yang divsteps,
+    p384/src/arithmetic/field.rs:67-91, primeorder/src/field.rs:505-559): the same field element as a^(p-2) by the Fermat
+    chain and as Python's pow(a, -1, p), on edge values and random ones."""
+    c = M.P384
+    rng = random.Random(384)
+    vals = [0, 1, 2, 3, c.p - 1, c.p - 2, (c.p - 1) // 2, (c.p + 1) // 2, 1 << 383, (1 << 383) - 1, 1 << 192] + [rng.randrange(c.p) for _ in range(300)]
+    a = arr([v.to_bytes(48, "big") for v in vals], 48)
+    by = CO.p384_invert(a)
+    fe = CO.p384_invert(a, fermat=True)
+    assert bytes(by) == bytes(fe)
+    for v, row in zip(vals, by):
+        assert int.from_bytes(bytes(row), "big") == (pow(v, -1, c.p) if v else 0), hex(v)

@@ -44,7 +44,7 @@ def main():
     import bench
     # provenance: which workload of bench.py, the commit the tree was at (passed in: the GPU box has no .git) and the hash of
     # the kernel sources that were profiled - bench.py recomputes the hash and says whether the sources have changed since
-    res = {"workload": workload, "commit": commit, "csrc_sha16": bench.csrc_sha16(), "kernel_match": match, "counters_per_launch": per, "kernel_trace": dur}
+    res = {"workload": workload, "commit": commit, "csrc_sha16": bench.csrc_sha16(workload), "kernel_match": match, "counters_per_launch": per, "kernel_trace": dur}
     if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
         raw = (per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
         x2 = (2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
