@@ -60,11 +60,15 @@ for cn in ("k256", "p256", "p384"):
     enc = torch.empty((n, nb + 1), **u8)
     timed("to_bytes (SEC1 compressed)", cn, lambda: lib.ecgpu_to_bytes_batch(h, cid, P(p), 0, P(enc), n, 1))
     timed("from_bytes", cn, lambda: lib.ecgpu_from_bytes_batch(h, cid, P(enc), P(xy), P(f), n, 1))
+    unc = torch.empty((n, 2 * nb + 1), **u8)
+    timed("sec1_encode (uncompressed)", cn, lambda: lib.ecgpu_sec1_encode_batch(h, cid, P(p), 0, 0, P(unc), n, 1))
+    timed("sec1_decode (uncompressed)", cn, lambda: lib.ecgpu_sec1_decode_batch(h, cid, P(unc), 2 * nb + 1, P(xy), P(f), n, 1))
     timed("map_to_curve (2 elements, sum)", cn, lambda: lib.ecgpu_map_to_curve_batch(h, cid, P(torch.cat([x, y], 1)), 2, P(xy), P(f), n, 1))
     timed("mul_by_generator (throughput)", cn, lambda: cv.mul_device(s, None, xy, n))
     timed("mul_by_generator (reference, CT)", cn, lambda: cv.mul_device(s, None, xy, n, flags=ecgpu.EXACT_REFERENCE))
     timed("mul (throughput)", cn, lambda: cv.mul_device(s, p, xy, n))
     timed("mul (reference, CT)", cn, lambda: cv.mul_device(s, p, xy, n, flags=ecgpu.EXACT_REFERENCE), reps=2)
+    timed("mul (SECRET_SCALARS: ECDH)", cn, lambda: cv.mul_device(s, p, xy, n, flags=ecgpu.SECRET_SCALARS), reps=2)
     keys = torch.empty((n, 2 * nb), **u8); sig = torch.empty((n, 2 * nb), **u8); rec = torch.empty((n,), **u8)
     cv.mul_device(s, None, keys, n)
     fl = cv.default_ecdsa_flags()
