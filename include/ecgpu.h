@@ -306,6 +306,16 @@ int ecgpu_ecdsa_recover_batch(ecgpu_ctx* ctx, int curve, const uint8_t* prehash,
                               const uint8_t* recovery_id, uint8_t* pubkeys_xy, uint8_t* ok, size_t n, int mem,
                               unsigned flags);
 
+/* ---- ECDH over the path -------------------------------------------------------------------------------------------------
+ * elliptic_curve::ecdh::diffie_hellman for a batch (external elliptic-curve 0.13.8; re-exported at k256/src/ecdh.rs:41,
+ * p256/src/ecdh.rs, p384/src/ecdh.rs): shared_x[i] = x((pubkeys[i] * secret[i]).to_affine()), the bytes SharedSecret holds
+ * (k256 ecdh.rs:51-55).  ok[i] = 0 and zeros where the reference's types could not have been built: a secret scalar that
+ * is zero or >= n (NonZeroScalar), a public key that is non-canonical, off the curve or the identity (PublicKey).
+ * The multiplication is the ECGPU_SECRET_SCALARS one (constant-time); staged copies of the secrets AND of the shared
+ * values are cleared before the call returns, the intermediate products do not stay in the context's workspace. */
+int ecgpu_ecdh_batch(ecgpu_ctx* ctx, int curve, const uint8_t* secret_scalars, const uint8_t* pubkeys_xy, uint8_t* shared_x,
+                     uint8_t* ok, size_t n, int mem);
+
 /* ---- BIP340 Schnorr over secp256k1 -----------------------------------------------------------------
  * The elliptic-curve part of VerifyingKey::verify_prehash (k256/src/schnorr/verifying.rs:62-93): with the challenge
  * e = tagged_hash("BIP0340/challenge", r || P.x || m) supplied by the caller (32 bytes, reduced mod n here),

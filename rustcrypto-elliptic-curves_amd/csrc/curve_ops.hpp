@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 #include "fixedbase.hpp"
 #include "ecdsa_kernels.hpp"
+#include "ecdh_kernels.hpp"
 #include "sec1_kernels.hpp"
 #include "schnorr_kernels.hpp"
 #include "h2c_kernels.hpp"
@@ -363,6 +364,21 @@ struct CurveOps {
       return 0;
     }
   }
+  // ECDH (ecdh_kernels.hpp): input checks, the secret-scalar multiplication (constant-time kernel where the curve has
+  // one, the reference schedule otherwise), x of the product
+  static int ecdh(ecgpu_ctx* c, const u32* d, const u32* q, u32* shared_x, uint8_t* ok, size_t n) {
+    int rc = ecdsa_reserve(c, al256(n * 2 * C::NB));
+    if (rc) return rc;
+    u32* prod = (u32*)c->ecdsa_ws;
+    hipLaunchKernelGGL((ecdh::prep_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, d, q, ok, n);
+    HIPCHK(c, hipGetLastError());
+    if ((rc = lincomb(c, d, q, FMT_AFFINE, 1, prod, FMT_AFFINE, nullptr, n, (unsigned)ECGPU_SECRET_SCALARS))) return rc;
+    hipLaunchKernelGGL((ecdh::finish_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, (const u32*)prod, (const uint8_t*)ok, shared_x, n);
+    HIPCHK(c, hipGetLastError());
+    // the products are secrets of the same rank as the shared values handed back: they do not stay in the workspace
+    HIPCHK(c, hipMemsetAsync(prod, 0, n * 2 * C::NB, c->stream));
+    return 0;
+  }
   static int ecdsa_sign(ecgpu_ctx* c, const u32* d, const u32* k, const u32* z, u32* sig, uint8_t* recid, uint8_t* ok, size_t n,
                         unsigned flags) {
     const size_t sz_p = al256(n * 2 * C::NB), sz_f = al256(n);
@@ -384,7 +400,7 @@ struct CurveOps {
   }
   static const ecgpu_curve_ops* table() {
     static const ecgpu_curve_ops t = {field_op, point_op, point_eq, normalize, lincomb, msm, validate_scalars, validate_points,
-                                      decompress, synth_scalars, synth_points, to_bytes, from_bytes, sec1_encode, sec1_decode, ecdsa_verify, h2c_map, ecdsa_recover, schnorr_verify, ecdsa_sign};
+                                      decompress, synth_scalars, synth_points, to_bytes, from_bytes, sec1_encode, sec1_decode, ecdsa_verify, h2c_map, ecdsa_recover, schnorr_verify, ecdsa_sign, ecdh};
     return &t;
   }
 };

@@ -733,6 +733,32 @@ int ecgpu_ecdsa_sign_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, con
   return finish_host(c, mem);
 }
 
+int ecgpu_ecdh_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, const uint8_t* pubkeys_xy, uint8_t* shared_x, uint8_t* ok, size_t n, int mem) {
+  if (!c || !secret_d || !pubkeys_xy || !shared_x || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  if (n == 0) return ECGPU_OK;
+  ENTER(c, curve);
+  SecretWipe wipe(c);                        // the staged secret scalars are cleared on every exit path
+  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
+    for (int sl = 0; sl < 2; sl++) { wipe.arm(6 + sl * PIPE_MAXARGS, PIPE_CHUNK * nb); wipe.arm(6 + sl * PIPE_MAXARGS + 2, PIPE_CHUNK * nb); }   // secrets, shared values
+    const PipeArg args[4] = {{secret_d, nullptr, nb}, {pubkeys_xy, nullptr, 2 * nb}, {nullptr, shared_x, nb}, {nullptr, ok, 1}};
+    return host_pipeline(c, args, 4, n, [&](void** d, size_t cnt) {
+      return ops->ecdh(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (uint32_t*)d[2], (uint8_t*)d[3], cnt);
+    });
+  }
+  Buf bd, bq, bs, bo;
+  int rc;
+  if (mem == ECGPU_MEM_HOST) wipe.arm(0, n * nb);
+  if ((rc = buf_in(c, bd, 0, secret_d, n * nb, mem))) return rc;
+  if ((rc = buf_in(c, bq, 1, pubkeys_xy, n * 2 * nb, mem))) return rc;
+  if ((rc = buf_out(c, bs, 2, shared_x, n * nb, mem))) return rc;
+  if ((rc = buf_out(c, bo, 3, ok, n, mem))) return rc;
+  if ((rc = ops->ecdh(c, (const uint32_t*)bd.dev, (const uint32_t*)bq.dev, (uint32_t*)bs.dev, (uint8_t*)bo.dev, n))) return rc;
+  if ((rc = buf_finish(c, bs))) return rc;
+  if ((rc = buf_finish(c, bo))) return rc;
+  if (mem == ECGPU_MEM_HOST) wipe.arm(2, n * nb);   // the staged copy of the shared secrets goes as well (after the download, ordered on the stream)
+  return finish_host(c, mem);
+}
+
 int ecgpu_synth_scalars(ecgpu_ctx* c, int curve, uint64_t seed, uint64_t first, uint8_t* d_scalars, size_t n) {
   if (!c || !d_scalars) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
   if (n == 0) return ECGPU_OK;

@@ -99,6 +99,7 @@ struct ecgpu_curve_ops {
   int (*schnorr_verify)(ecgpu_ctx* c, const uint32_t* px, const uint32_t* sig, const uint32_t* e, uint8_t* ok, size_t n);
   int (*ecdsa_sign)(ecgpu_ctx* c, const uint32_t* d, const uint32_t* k, const uint32_t* z, uint32_t* sig, uint8_t* recid, uint8_t* ok,
                     size_t n, unsigned flags);
+  int (*ecdh)(ecgpu_ctx* c, const uint32_t* d, const uint32_t* q_xy, uint32_t* shared_x, uint8_t* ok, size_t n);
 };
 // Pippenger MSM, one translation unit per curve (msm_*.hip); `mul` is the curve's batch scalar multiplication (affine in / out
 // on device memory), used for small sums

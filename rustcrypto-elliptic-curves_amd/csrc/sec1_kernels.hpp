@@ -9,20 +9,42 @@
 namespace ecgpu {
 namespace sec1 {
 
-// affine x || y (zeros = identity) -> tag || x
+// affine x || y (zeros = identity) -> tag || x [|| y].  Records are 33 / 65 / 49 / 97 bytes, so a lane's own stores would be
+// byte stores at odd addresses (1.1x10^9 points/s for the 65-byte form); instead a workgroup lays its 256 records out in LDS
+// and copies the tile to HBM as consecutive dwords (a tile starts at a multiple of 256 records, hence 4-byte aligned).
 template <class C>
 __global__ void __launch_bounds__(256) to_bytes_kernel(const u32* xy, const uint8_t* inf, uint8_t* out, size_t n, int uncompressed) {
-  constexpr int NB = C::NB;
-  const int body = uncompressed ? 2 * NB : NB;
-  ECGPU_GRID_STRIDE(i, n) {
-    const uint8_t* src = (const uint8_t*)(xy + i * 2 * C::NW);
-    uint8_t* o = out + i * (size_t)(body + 1);
-    u32 z = 0;
+  constexpr int NB = C::NB, NW = C::NW;
+  const int body = uncompressed ? 2 * NB : NB, rec = body + 1;
+  __shared__ __align__(16) uint8_t tile[256 * (2 * NB + 1)];
+  for (size_t t0 = (size_t)blockIdx.x * 256; t0 < n; t0 += (size_t)gridDim.x * 256) {
+    const size_t i = t0 + threadIdx.x;
+    if (i < n) {
+      u32 w[2 * NW], z = 0;
 #pragma unroll
-    for (int j = 0; j < 2 * C::NW; j++) z |= xy[i * 2 * C::NW + j];
-    const bool id = (z == 0) || (inf && inf[i]);
-    o[0] = id ? 0 : (uncompressed ? (uint8_t)4 : (uint8_t)(2 + (src[2 * NB - 1] & 1)));
-    for (int j = 0; j < body; j++) o[1 + j] = id ? 0 : src[j];
+      for (int j = 0; j < 2 * NW; j++) { w[j] = xy[i * 2 * NW + j]; z |= w[j]; }
+      const bool id = (z == 0) || (inf && inf[i]);
+      uint8_t* o = tile + (size_t)threadIdx.x * rec;
+      // big-endian bytes in memory order: byte b of the record body is byte (b & 3) of word b >> 2; y's last byte decides the tag
+      o[0] = id ? 0 : (uncompressed ? (uint8_t)4 : (uint8_t)(2 + ((w[2 * NW - 1] >> 24) & 1)));
+#pragma unroll
+      for (int j = 0; j < 2 * NW; j++) {
+        if (4 * j < body) {
+          const u32 v = id ? 0u : w[j];
+          o[1 + 4 * j] = (uint8_t)v; o[2 + 4 * j] = (uint8_t)(v >> 8); o[3 + 4 * j] = (uint8_t)(v >> 16); o[4 + 4 * j] = (uint8_t)(v >> 24);
+        }
+      }
+    }
+    __syncthreads();
+    const size_t cnt = (n - t0 < 256) ? n - t0 : 256, bytes = cnt * rec;
+    uint8_t* dst = out + t0 * rec;
+    if ((((uintptr_t)dst) & 3) == 0) {
+      for (size_t q = threadIdx.x; q < bytes / 4; q += 256) ((u32*)dst)[q] = ((const u32*)tile)[q];
+      for (size_t b = (bytes & ~(size_t)3) + threadIdx.x; b < bytes; b += 256) dst[b] = tile[b];
+    } else {
+      for (size_t b = threadIdx.x; b < bytes; b += 256) dst[b] = tile[b];
+    }
+    __syncthreads();
   }
 }
 

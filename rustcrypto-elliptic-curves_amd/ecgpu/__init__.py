@@ -67,6 +67,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.ecgpu_set_option.argtypes = [vp, i, ctypes.c_int64]
     lib.ecgpu_get_option.argtypes = [vp, i, ctypes.POINTER(ctypes.c_int64)]
     lib.ecgpu_fb_table_bytes.argtypes = [vp, i, ctypes.POINTER(sz), ctypes.POINTER(i)]
+    lib.ecgpu_ecdh_batch.argtypes = [vp, i, u8p, u8p, u8p, u8p, sz, i]
     lib.ecgpu_sec1_encode_batch.argtypes = [vp, i, u8p, i, i, u8p, sz, i]
     lib.ecgpu_sec1_decode_batch.argtypes = [vp, i, u8p, sz, u8p, u8p, sz, i]
     lib.ecgpu_synchronize.argtypes = [vp]
@@ -110,7 +111,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
                  "ecgpu_lincomb_batch_checked", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_sign_batch", "ecgpu_to_bytes_batch",
                  "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch",
                  "ecgpu_ecdsa_recover_batch", "ecgpu_map_to_curve_batch", "ecgpu_use_own_stream", "ecgpu_last_error_copy",
-                 "ecgpu_set_option", "ecgpu_get_option", "ecgpu_fb_table_bytes", "ecgpu_sec1_encode_batch", "ecgpu_sec1_decode_batch"):
+                 "ecgpu_set_option", "ecgpu_get_option", "ecgpu_fb_table_bytes", "ecgpu_sec1_encode_batch", "ecgpu_sec1_decode_batch",
+                 "ecgpu_ecdh_batch"):
         getattr(lib, name).restype = ctypes.c_int
     if path is None:
         _lib = lib
@@ -126,7 +128,7 @@ EXPORTED_SYMBOLS = (
     "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch", "ecgpu_ecdsa_recover_batch", "ecgpu_map_to_curve_batch",
     "ecgpu_point_eq_batch", "ecgpu_mul_batch_checked", "ecgpu_lincomb_batch_checked",
     "ecgpu_use_own_stream", "ecgpu_last_error_copy", "ecgpu_set_option", "ecgpu_get_option", "ecgpu_fb_table_bytes",
-    "ecgpu_sec1_encode_batch", "ecgpu_sec1_decode_batch",
+    "ecgpu_sec1_encode_batch", "ecgpu_sec1_decode_batch", "ecgpu_ecdh_batch",
 )
 
 
@@ -349,8 +351,26 @@ class Curve:
         (k256/src/ecdh.rs:41-45).  Inputs are what the reference's types guarantee: non-zero scalars, valid keys.
         The scalars are secret: ECGPU_SECRET_SCALARS selects the constant-time variable-base kernel (csrc/varbase_ct.hpp) on
         P-256 / P-384 and the reference schedule, constant-time as well, on secp256k1."""
-        out, _ = self.mul(secret_scalars, public_keys_xy, flags=SECRET_SCALARS)
-        return np.ascontiguousarray(out[:, :self.nb])
+        shared, ok = self.ecdh(secret_scalars, public_keys_xy)
+        if not ok.all():
+            raise ValueError("diffie_hellman: element %d is not a NonZeroScalar / PublicKey pair" % int(np.argmin(ok)))
+        return shared
+
+    def ecdh(self, secret_scalars, public_keys_xy):
+        """ecgpu_ecdh_batch -> (shared_x (n, NB), ok (n,)): ok = 0 and zeros for a zero / out-of-range secret or an invalid key"""
+        d, q = _as_host(secret_scalars, self.nb), _as_host(public_keys_xy, 2 * self.nb)
+        if len(d) != len(q):
+            raise ValueError("secret and public-key batches differ in length")
+        out, ok = _host_out(len(d), self.nb), np.zeros(len(d), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ecgpu_ecdh_batch(self.ctx.handle, self.id, _ptr(d)[0], _ptr(q)[0], _ptr(out)[0], _ptr(ok)[0], len(d), HOST))
+        return out, ok
+
+    def ecdh_device(self, d_secret, d_pubkeys_xy, d_shared_x, d_ok, n: int):
+        self._check_device(d_secret, n * self.nb, "d_secret")
+        self._check_device(d_pubkeys_xy, n * 2 * self.nb, "d_pubkeys_xy")
+        self._check_device(d_shared_x, n * self.nb, "d_shared_x")
+        self._check_device(d_ok, n, "d_ok")
+        self.ctx.check(self.ctx.lib.ecgpu_ecdh_batch(self.ctx.handle, self.id, _ptr(d_secret)[0], _ptr(d_pubkeys_xy)[0], _ptr(d_shared_x)[0], _ptr(d_ok)[0], n, DEVICE))
 
     def _check_device(self, t, need_bytes: int, what: str):
         """size check for torch tensors handed to the *_device methods (raw integer pointers cannot be checked)"""

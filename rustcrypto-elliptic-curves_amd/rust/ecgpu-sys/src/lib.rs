@@ -101,6 +101,8 @@ extern "C" {
                                   recovery_id: *mut u8, ok: *mut u8, n: usize, mem: c_int, flags: c_uint) -> c_int;
     pub fn ecgpu_ecdsa_recover_batch(ctx: *mut ecgpu_ctx, curve: c_int, prehash: *const u8, sig_rs: *const u8, recovery_id: *const u8, pubkeys_xy: *mut u8,
                                      ok: *mut u8, n: usize, mem: c_int, flags: c_uint) -> c_int;
+    pub fn ecgpu_ecdh_batch(ctx: *mut ecgpu_ctx, curve: c_int, secret_scalars: *const u8, pubkeys_xy: *const u8, shared_x: *mut u8, ok: *mut u8, n: usize,
+                            mem: c_int) -> c_int;
     pub fn ecgpu_schnorr_verify_batch(ctx: *mut ecgpu_ctx, curve: c_int, pubkeys_x: *const u8, sig_rs: *const u8, challenges: *const u8, ok: *mut u8, n: usize,
                                       mem: c_int) -> c_int;
     pub fn ecgpu_map_to_curve_batch(ctx: *mut ecgpu_ctx, curve: c_int, u: *const u8, count: c_int, out_xy: *mut u8, out_inf: *mut u8, n: usize, mem: c_int) -> c_int;
@@ -306,6 +308,15 @@ impl Context {
             ecgpu_ecdsa_recover_batch(self.0, curve, prehash.as_ptr(), sig_rs.as_ptr(), recovery_id.as_ptr(), xy.as_mut_ptr(), ok.as_mut_ptr(), n, ECGPU_MEM_HOST, flags)
         })?;
         Ok((xy, ok))
+    }
+    /// elliptic_curve::ecdh::diffie_hellman for a batch -> (x of the shared points, ok flags); constant-time multiplication
+    pub fn ecdh(&self, curve: c_int, secret_scalars: &[u8], pubkeys_xy: &[u8]) -> Result<(Vec<u8>, Vec<u8>), Error> {
+        let nb = Self::field_bytes(curve);
+        Self::arg(nb != 0 && secret_scalars.len() % nb == 0 && pubkeys_xy.len() == 2 * secret_scalars.len())?;
+        let n = secret_scalars.len() / nb;
+        let (mut shared, mut ok) = (vec![0u8; nb * n], vec![0u8; n]);
+        self.check(unsafe { ecgpu_ecdh_batch(self.0, curve, secret_scalars.as_ptr(), pubkeys_xy.as_ptr(), shared.as_mut_ptr(), ok.as_mut_ptr(), n, ECGPU_MEM_HOST) })?;
+        Ok((shared, ok))
     }
     /// the elliptic-curve part of BIP340 verification (challenges = tagged hashes, 32 bytes each)
     pub fn schnorr_verify(&self, pubkeys_x: &[u8], sig_rs: &[u8], challenges: &[u8]) -> Result<Vec<u8>, Error> {

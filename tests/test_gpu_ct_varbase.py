@@ -127,3 +127,56 @@ def test_ecdh_uses_the_secret_scalar_schedule(cname, cid):
         one = (1).to_bytes(nb, "big")
         assert all(bytes(proj[i][:nb]) == bytes(s1[i]) and bytes(proj[i][2 * nb:]) == one for i in range(n))
     ctx.close()
+
+
+@pytest.mark.parametrize("cname,cid", [("p256", 1), ("p384", 2), ("k256", 0)])
+def test_ecdh_batch_entry_point(cname, cid):
+    """ecgpu_ecdh_batch: x((public * secret).to_affine()) with the checks the reference's types perform on construction -
+    NonZeroScalar (0 < d < n), PublicKey (canonical, on the curve, not the identity); host buffers, device buffers, and
+    the 2^21-unit host pipeline agree."""
+    import torch
+    import ecgpu
+    c = synth.M.CURVES[cname]
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cname)
+    nb = cv.nb
+    n = 500
+    d = CO.synth_scalars(cid, n, synth.SEED, 12_000)
+    q = CO.synth_points(cid, n, synth.SEED, 12_000)
+    d[3] = 0                                                                     # zero secret
+    d[4] = np.frombuffer(int(c.n).to_bytes(nb, "big"), dtype=np.uint8)            # = n
+    d[5] = np.frombuffer(int(c.n - 1).to_bytes(nb, "big"), dtype=np.uint8)        # fine
+    q[6] = 0                                                                     # identity encoding
+    q[7][-1] ^= 1                                                                # off the curve
+    q[8][:nb] = np.frombuffer(int(c.p).to_bytes(nb, "big"), dtype=np.uint8)       # x = p
+    shared, ok = cv.ecdh(d, q)
+    bad = {3, 4, 6, 7, 8}
+    assert ok.tolist() == [0 if i in bad else 1 for i in range(n)]
+    want = CO.lincomb_batch(cid, d, q, threads=THREADS)
+    for i in range(n):
+        if i in bad:
+            assert not shared[i].any(), i
+        else:
+            assert bytes(shared[i]) == bytes(want[i][:nb]) and want[i][-1] == 0, i
+    d_d, d_q = torch.from_numpy(d).cuda(), torch.from_numpy(q).cuda()
+    d_s = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
+    d_ok = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    cv.ecdh_device(d_d, d_q, d_s, d_ok, n)
+    ctx.synchronize()
+    assert bytes(d_s.cpu().numpy()) == bytes(shared) and bytes(d_ok.cpu().numpy()) == bytes(ok)
+    if cid == 1:                                 # the chunked host pipeline (>= 2^21 units) against the device path
+        m = (1 << 21) + 333
+        dm = CO.synth_scalars(cid, m, synth.SEED, 13_000)
+        qm = CO.synth_points(cid, m, synth.SEED, 13_000)
+        dm[m - 5] = 0
+        sh, okm = cv.ecdh(dm, qm)
+        d_dm, d_qm = torch.from_numpy(dm).cuda(), torch.from_numpy(qm).cuda()
+        d_sm = torch.empty((m, nb), dtype=torch.uint8, device="cuda")
+        d_okm = torch.empty((m,), dtype=torch.uint8, device="cuda")
+        cv.ecdh_device(d_dm, d_qm, d_sm, d_okm, m)
+        ctx.synchronize()
+        assert bytes(d_sm.cpu().numpy()) == bytes(sh) and bytes(d_okm.cpu().numpy()) == bytes(okm) and okm.sum() == m - 1
+        idx = np.arange(0, m, m // 2000)
+        w = CO.lincomb_batch(cid, dm[idx], qm[idx], threads=THREADS)
+        assert bytes(sh[idx]) == bytes(w[:, :nb])
+    ctx.close()
