@@ -69,16 +69,17 @@ WORK = {
     # 10 signed 26-bit windows (21.5 GB table): 9 mixed additions (the first is a copy) + normalise 6M+1S + (255S+12M)/64
     "p256_fixedbase": (9 * 8 + 6 + 12 / 64, 9 * 3 + 1 + 255 / 64),
     # 96 windows x 4 doublings (4M+4S) + 89 mixed additions (97 digits x 15/16, first one a copy) + table (4 dbl,
-    # 3 general additions 11M+5S) + table to affine 8 x (6M+1S) + (385S+14M)/8 + output normalise 6M+1S + (385S+14M)/8
-    "p384_varbase": (1536 + 89 * 8 + 49 + 48 + 14 / 8 + 6 + 14 / 8, 1536 + 89 * 3 + 31 + 8 + 385 / 8 + 1 + 385 / 8),
+    # 3 general additions 11M+5S) + table to affine 8 x (6M+1S) + (385S+14M)/16 + output normalise 6M+1S + (385S+14M)/16
+    # (16 units per lane and pass share the two inversions since round 3; 8 before)
+    "p384_varbase": (1536 + 89 * 8 + 49 + 48 + 14 / 16 + 6 + 14 / 16, 1536 + 89 * 3 + 31 + 8 + 385 / 16 + 1 + 385 / 16),
     # bucket method with GLV halves, 7 windows of 18 / 19 bits at this size: 14 XYZZ mixed additions (8M+2S) per term;
     # per-term share of the endomorphism (1M), of the bucket pieces and of the bucket reduction (1.8 M buckets: XYZZ -> Jacobian
     # and two general additions 12M+4S each; 1.5 M pieces folded) ~ 9M + 3S
     "k256_msm": (14 * 8 + 1 + 9, 14 * 2 + 3),
     # verification = u2 Q (headline kernel) + u1 G (20-bit table at this batch size) + prep / check (57 scalar-field equivalents + 7)
     "k256_ecdsa_verify": (87 + 128 * 3 + 66 * 15 / 16 * 8 + 9 + 12 * 8 + 6 + 64, 29 + 128 * 4 + 66 * 15 / 16 * 3 + 9 + 12 * 3 + 5),
-    # p256 verification = u2 Q (vb::mul_kernel<CurveP256,8,4>: 256 doublings 4M+4S, 60 general additions 11M+5S, table 4 dbl + 3 add,
-    # output normalise 6M+1S + (255S+12M)/8 = 1 740 M + 1 388 S) + u1 G (20-bit table: 102 M + 41 S) + prep / check (~64 M)
+    # p256 verification = u2 Q (vb::mul_kernel<CurveP256,16,4>: 256 doublings 4M+4S, 60 general additions 11M+5S, table 4 dbl + 3 add,
+    # output normalise 6M+1S + (255S+12M)/8 = 1 740 M + 1 388 S; counted with 8 units per inversion, 16 since round 3: -1 %) + u1 G (20-bit table: 102 M + 41 S) + prep / check (~64 M)
     "p256_ecdsa_verify": (1740 + 102 + 64, 1388 + 41),
 }
 
@@ -90,7 +91,7 @@ WORKLOADS = {
                            bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,26,64,4>", pmc_match="P256Params>, 26, 64, 4",
                            desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
     "p384_varbase": dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
-                         bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,8,4>", pmc_match="vb::mul_kernel",
+                         bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,16,4>", pmc_match="vb::mul_kernel",
                          desc="p384 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
     "k256_msm": dict(curve="k256", cid=0, log2n=23, fixed=False, msm=True, metric="k256 MSM points/sec", unit="points/s",
                      bytes_per_unit=32 + 64, kernel="msm pipeline (digits / sort / bucket sums / reduce)", pmc_match="bucket_sum_kernel",
@@ -99,7 +100,7 @@ WORKLOADS = {
                               bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + k256_mul_fast_kernel<32,4> + verify_check", pmc_match="k256_mul_fast_kernel",
                               desc="k256 ECDSA verify_prehashed (low-s rule), 2^%d independent (prehash, signature, public key) triples per GPU"),
     "p256_ecdsa_verify": dict(curve="p256", cid=1, log2n=22, fixed=False, msm=False, ecdsa=True, metric="p256 ECDSA verifications/sec", unit="verifications/s",
-                              bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + vb::mul_kernel<CurveP256,8,4> + verify_check", pmc_match="vb::mul_kernel",
+                              bytes_per_unit=32 + 64 + 64 + 1, kernel="verify_prep + fb::mul_wide_kernel + vb::mul_kernel<CurveP256,16,4> + verify_check", pmc_match="vb::mul_kernel",
                               desc="p256 ECDSA verify_prehashed, 2^%d independent (prehash, signature, public key) triples per GPU"),
 }
 OTHER_CONFIGS = ("p256_fixedbase", "k256_msm", "p384_varbase")      # BASELINE.json configs 3, 4 (one GPU's share), 5

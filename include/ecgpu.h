@@ -147,7 +147,7 @@ typedef enum ecgpu_option {
                                      the library itself when an allocation fails, setting it again lifts that */
   ECGPU_OPT_MSM_WINDOW_BITS = 2,  /* bucket-method window: 16 | 19, 0 = the size rule [0] */
   ECGPU_OPT_MSM_SLAB_TERMS = 3,   /* terms per slab of a large sum, 1024 .. the window's maximum, 0 = that maximum [0] */
-  ECGPU_OPT_MSM_SMALL_PATH = 4,   /* 1: sums below 2^13 terms run as scalar multiplications and a tree sum, 0: always buckets [1] */
+  ECGPU_OPT_MSM_SMALL_PATH = 4,   /* 1: sums below 5 * 2^14 terms run as scalar multiplications and a tree sum, 0: always buckets [1] */
   ECGPU_OPT_MSM_ROUNDS = 5,       /* bucket-sum runs per resident lane, 1 .. 64, 0 = default [0] */
   ECGPU_OPT_K256_WAVES = 6,       /* occupancy variant of the secp256k1 variable-base kernel: 3 | 4 waves per SIMD [4] */
   ECGPU_OPT_FB_MEMORY_BUDGET = 7, /* bytes of device memory the generator tables of ONE curve may take in this context,

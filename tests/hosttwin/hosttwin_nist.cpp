@@ -100,9 +100,8 @@ extern "C" int ht_jac_op(int curve, int op, const uint8_t* p, const uint8_t* q, 
 // The kernel gives lane tid the units tid, tid + T, ... in passes of BATCH; here T = lanes is small, so a few hundred
 // units exercise every slot count 1..BATCH, several passes, the shared table inversion and the batched output.
 #include "varbase_lane.hpp"
-template <class C, int NT>
+template <class C, int NT, int BATCH = 8>
 static int vb_walk(const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, size_t lanes) {
-  constexpr int BATCH = 8;
   vb::LaneWs<C, BATCH>* ws = (vb::LaneWs<C, BATCH>*)malloc(sizeof(vb::LaneWs<C, BATCH>));
   u32 digits[NT * C::NW];
   const DigitMem dm{digits, 1};
@@ -121,6 +120,12 @@ extern "C" int ht_vb_lincomb(int curve, const uint8_t* scalars, const uint8_t* p
   return curve == 1 ? vb_walk<CurveP256, 1>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes)
                     : vb_walk<CurveP384, 1>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
 }
+// the product's own pass size (VBB = 16 table slots per lane and pass, ops_nist.inc)
+extern "C" int ht_vb_mul16(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
+                           size_t lanes) {
+  return curve == 1 ? vb_walk<CurveP256, 1, 16>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes)
+                    : vb_walk<CurveP384, 1, 16>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
+}
 extern "C" int ht_vb_mul(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
                          size_t lanes) {
   return ht_vb_lincomb(curve, scalars, points, pt_fmt, 1, out, out_fmt, out_inf, n, lanes);
@@ -130,9 +135,8 @@ extern "C" int ht_vb_mul(int curve, const uint8_t* scalars, const uint8_t* point
 //      workspace of stride `lanes`, exactly as the kernel lays it out with stride 256.  The trace hook records the table
 //      entries the window loop reads.
 #include "varbase_ct.hpp"
-template <class C>
+template <class C, int BATCH = 8>
 static int vbct_walk(const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, size_t lanes) {
-  constexpr int BATCH = 8;
   vbct::Chunk* mem = (vbct::Chunk*)aligned_alloc(16, sizeof(vbct::Chunk) * vbct::lane_chunks<C, BATCH>() * lanes);
   memset(mem, 0xA5, sizeof(vbct::Chunk) * vbct::lane_chunks<C, BATCH>() * lanes);
   u32 digits[C::NW];
@@ -144,6 +148,11 @@ static int vbct_walk(const uint8_t* scalars, const uint8_t* points, int pt_fmt, 
   }
   free(mem);
   return 0;
+}
+extern "C" int ht_vbct_mul16(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
+                             size_t lanes) {
+  return curve == 1 ? vbct_walk<CurveP256, 16>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes)
+                    : vbct_walk<CurveP384, 16>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
 }
 extern "C" int ht_vbct_mul(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
                            size_t lanes) {

@@ -3,8 +3,8 @@
 P-256 / P-384 run `vbct::mul_kernel` (Jacobian doublings, masked scans of per-lane affine tables, exception-free by the
 fold k -> min(k, n - k)); secp256k1 has no dedicated kernel and takes the reference schedule (GLV + complete formulas),
 which is constant-time as well.  Every curve is compared with the C oracle at 2^20 units:
-with 262 144 resident lanes that is 4 table slots per lane, so the shared table inversion and the batched output run
-over several units; a second, ragged case adds a second pass.  Planted: zero, one, n - 1, the scalars a windowed
+with 262 144 (P-384: 196 608) resident lanes that is 4 to 6 table slots per lane, so the shared table inversion and the
+batched output run over several units; a second, ragged case adds a second pass.  Planted: zero, one, n - 1, the scalars a windowed
 Jacobian schedule without the fold would break on (n - 2, n - 6, n - 16 .. n - 1), (n +- 1) / 2, scalars >= n, identity
 points, and the same point with k and n - k.
 """
@@ -91,8 +91,9 @@ def test_secret_scalar_variable_base_2p20(cname, cid):
 
 @pytest.mark.parametrize("cname,cid", [("p256", 1), ("p384", 2)])
 def test_secret_scalar_variable_base_two_passes(cname, cid):
-    """2^21 + 2^18 + 777 units: a full pass of 8 slots per lane and a ragged second pass."""
-    _run(cname, cid, (1 << 21) + (1 << 18) + 777, 80_000_000 + cid, sample_all=False)
+    """2^22 + 2^18 + 777 units: a full pass of 16 slots per lane (262 144 lanes at 4 waves per SIMD on P-256, 196 608 at 3 on
+    P-384) and a ragged second pass."""
+    _run(cname, cid, (1 << 22) + (1 << 18) + 777, 80_000_000 + cid, sample_all=False)
 
 
 @pytest.mark.parametrize("cname,cid", [("p256", 1), ("p384", 2), ("k256", 0)])

@@ -5,8 +5,8 @@ The variable-base kernels launch at most 4 workgroups per CU (262 144 lanes on 2
 lane holds ONE result.  Only at the BASELINE sizes does a lane carry several results per pass (slots b > 0 of its
 table workspace, the shared table inversion over all of them, the batched output inversion) and come back for a
 second pass:
-    config 5  p384  2^22 units:  8 slots per lane, two passes
-    p256      2^21 + 2^19 units: 8 slots, then a ragged second pass of 2
+    config 5  p384  2^22 units:  16 slots per lane, exactly one pass; 2^22 + 2^20 + 321: a ragged second pass
+    p256      2^22 + 2^19 units: 16 slots, then a ragged second pass of 2
     config 2  k256  2^24 units:  32 results per lane per pass, two passes
 Edge inputs (zero scalar, identity point, scalar >= n) are planted in slots b > 0 and in the second pass.
 """
@@ -49,7 +49,7 @@ def _run_varbase(cname, cid, n, first, edges):
     order = {0: synth.M.K256.n, 1: synth.M.P256.n, 2: synth.M.P384.n}[cid]
     planted = []
     for slot, pass_, lane, kind in edges(lanes):
-        i = pass_ * lanes * (32 if cid == 0 else 8) + slot * lanes + lane
+        i = pass_ * lanes * (32 if cid == 0 else 16) + slot * lanes + lane
         if i >= n:
             continue
         if kind == "zero":
@@ -64,7 +64,7 @@ def _run_varbase(cname, cid, n, first, edges):
     torch.cuda.synchronize()
     cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i)
     ctx.synchronize()
-    idx = np.unique(np.concatenate([_sample_indices(n, lanes, lanes * (32 if cid == 0 else 8)), np.array([i for i, _ in planted], dtype=np.int64)]))
+    idx = np.unique(np.concatenate([_sample_indices(n, lanes, lanes * (32 if cid == 0 else 16)), np.array([i for i, _ in planted], dtype=np.int64)]))
     t_idx = torch.from_numpy(idx).cuda()
     s = d_s[t_idx].cpu().numpy()
     p = d_p[t_idx].cpu().numpy()
@@ -95,13 +95,19 @@ def _edges(lanes):
 
 
 def test_p384_config5_2p22():
-    """BASELINE config 5 at its own size: vb::mul_kernel<CurveP384, 8, 4>, 8 slots per lane, two passes."""
+    """BASELINE config 5 at its own size: vb::mul_kernel<CurveP384, 16, 4>, 16 slots per lane, one full pass (the planted
+    "second pass" indices fall into slots 8..15)."""
     assert _run_varbase("p384", 2, 1 << 22, 40_000_000, _edges) >= 32768 + 8192
 
 
+def test_p384_varbase_second_pass():
+    """p384 with a full pass of 16 slots and a ragged second pass (4 slots and a partial fifth)."""
+    assert _run_varbase("p384", 2, (1 << 22) + (1 << 20) + 321, 41_000_000, _edges) >= 32768 + 8192
+
+
 def test_p256_varbase_2p21_plus():
-    """p256 variable base with a full pass of 8 slots and a ragged second pass (2 slots, last one partial)."""
-    assert _run_varbase("p256", 1, (1 << 21) + (1 << 19) + 12345, 50_000_000, _edges) >= 32768 + 8192
+    """p256 variable base with a full pass of 16 slots and a ragged second pass (2 slots and a partial third)."""
+    assert _run_varbase("p256", 1, (1 << 22) + (1 << 19) + 12345, 50_000_000, _edges) >= 32768 + 8192
 
 
 def test_k256_config2_2p24_second_pass():

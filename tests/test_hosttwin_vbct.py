@@ -20,7 +20,7 @@ from hosttwin_util import lib, buf, outbuf
 CURVES = [("p256", 1), ("p384", 2)]
 
 
-def _vbct(cid, c, ks, ps, lanes, out_fmt=0, proj_in=False):
+def _vbct(cid, c, ks, ps, lanes, out_fmt=0, proj_in=False, fn="ht_vbct_mul"):
     nb = c.nbytes
     n = len(ks)
     sb = b"".join(int(k).to_bytes(nb, "big") for k in ks)
@@ -31,9 +31,9 @@ def _vbct(cid, c, ks, ps, lanes, out_fmt=0, proj_in=False):
     out = outbuf((3 if out_fmt else 2) * nb * n)
     inf = outbuf(n)
     L = lib()
-    L.ht_vbct_mul.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                              ctypes.c_size_t, ctypes.c_size_t]
-    assert L.ht_vbct_mul(cid, buf(sb), buf(pb), 1 if proj_in else 0, out, out_fmt, inf, n, lanes) == 0
+    f = getattr(L, fn)
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
+    assert f(cid, buf(sb), buf(pb), 1 if proj_in else 0, out, out_fmt, inf, n, lanes) == 0
     return bytes(out), bytes(inf)
 
 
@@ -88,6 +88,27 @@ def test_vbct_slot_counts_and_passes(cn, cid, lanes, n):
         ks[min(lanes * 9, n - 1)] = c.n - 2
         ps[lanes * 4 + 1] = None
     out, inf = _vbct(cid, c, ks, ps, lanes)
+    for i in range(n):
+        want = None if ps[i] is None else M.affine_mul(c, ks[i] % c.n, ps[i])
+        got = out[2 * nb * i:2 * nb * (i + 1)]
+        if want is None:
+            assert got == bytes(2 * nb) and inf[i] == 1, i
+        else:
+            assert got == M.i2b(c, want[0]) + M.i2b(c, want[1]) and inf[i] == 0, i
+
+
+@pytest.mark.parametrize("cn,cid", CURVES)
+@pytest.mark.parametrize("fn", ["ht_vbct_mul16", "ht_vb_mul16"])
+def test_sixteen_slots_per_pass(cn, cid, fn):
+    """The product's pass size (16 table slots per lane and pass): 2 lanes, 53 units = one full pass and a ragged second one
+    (11 and 10 slots), for the constant-time body and for the public-data body."""
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    n, lanes = 53, 2
+    ks = [synth.scalar(c, 7000 + i) for i in range(n)]
+    ps = [synth.point(c, 7000 + i) for i in range(n)]
+    ks[31], ks[33], ks[40], ps[17], ps[50] = 0, c.n - 2, c.n - 6, None, None
+    out, inf = _vbct(cid, c, ks, ps, lanes, fn=fn)
     for i in range(n):
         want = None if ps[i] is None else M.affine_mul(c, ks[i] % c.n, ps[i])
         got = out[2 * nb * i:2 * nb * (i + 1)]
