@@ -16,7 +16,7 @@ if [ "$part" = A ]; then
   prof p384_varbase
   timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d gpurun_out/ct -- python3 tools/ct_evidence.py > "$O/ct.log" 2>&1; echo "ct rc=$?"
   python3 tools/ct_summarize.py gpurun_out/ct > "$O/ct_counters.txt"; rm -rf gpurun_out/ct
-  grep -c "identical across the scalar sets: True" "$O/ct_counters.txt"
+  grep -c "counters identical: True" "$O/ct_counters.txt" || true
 else
   prof p256_fixedbase
   prof k256_msm
