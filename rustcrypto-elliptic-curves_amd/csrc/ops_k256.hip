@@ -1,5 +1,6 @@
 // secp256k1 kernels and launchers (one translation unit per curve: the library builds in parallel).
 #include "curve_ops.hpp"
+#include "varbase_ct_k256.hpp"
 using namespace ecgpu;
 #ifndef K256_FAST_BATCH
 #define K256_FAST_BATCH 32   // results per lane that share one inversion in the variable-base kernel (16: -0.4 %)
@@ -34,9 +35,38 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
   HIPCHK(c, hipGetLastError());
   return 1;
 }
-// secret scalars on a variable base: the reference schedule (GLV + complete formulas, masked scans) is the constant-time one here
+// secret scalars on a variable base (ECDH): varbase_ct_k256.hpp - complete formulas over per-lane AFFINE tables, one masked scan per
+// window for both GLV halves, shared inversions; K256_CT_BATCH units per lane and pass
+#ifndef K256_CT_BATCH
+#define K256_CT_BATCH 16
+#endif
+#ifndef K256_CT_WAVES
+#define K256_CT_WAVES 3        // 168 VGPRs: 47.8 ms per 2^22 against 49.6 ms at 4 waves per SIMD (128 VGPRs, 114 spilled) and 49.5 ms at 2
+#endif
+template <int BATCH, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k256_mul_ct_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf,
+                                                                 size_t n, vbct::Chunk* ws_all) {
+  const vbct::LaneMem ws{ws_all + (size_t)blockIdx.x * vbct::lane_chunks<CurveK256, BATCH>() * 256 + threadIdx.x, 256};
+  __shared__ u32 lds_digits[8][256];
+  const DigitMem dm{&lds_digits[0][threadIdx.x], 256};
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t base = tid; base < n; base += T * BATCH) vbct::lane_pass_k256<BATCH>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, base, T, ws, dm);
+}
 template <>
-int CurveOps<CurveK256>::mul_ct(ecgpu_ctx*, const u32*, const u32*, int, u32*, int, uint8_t*, size_t) { return 0; }
+int CurveOps<CurveK256>::mul_ct(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
+  const dim3 grid(ecgpu_grid_for(c, n, K256_CT_WAVES));
+  const size_t ws_need = (size_t)grid.x * 256 * vbct::lane_chunks<CurveK256, K256_CT_BATCH>() * sizeof(vbct::Chunk);
+  if (ws_need > c->tab_ws_cap) {
+    if (c->tab_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->tab_ws)); c->tab_ws = nullptr; c->tab_ws_cap = 0; }
+    HIPCHK(c, hipMalloc(&c->tab_ws, ws_need));
+    c->tab_ws_cap = ws_need;
+  }
+  hipLaunchKernelGGL((k256_mul_ct_kernel<K256_CT_BATCH, K256_CT_WAVES>), grid, dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n,
+                     (vbct::Chunk*)c->tab_ws);
+  HIPCHK(c, hipGetLastError());
+  return 1;
+}
 // Pippenger MSM (msm.hpp, msm_kernels.hpp; instantiated in msm_k256.hip)
 static int k256_mul_for_msm(ecgpu_ctx* c, const u32* s, const u32* p, int fmt, u32* prod, size_t cnt) {
   return CurveOps<CurveK256>::lincomb(c, s, p, fmt, 1, prod, FMT_AFFINE, nullptr, cnt, 0);

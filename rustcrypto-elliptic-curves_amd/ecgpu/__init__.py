@@ -349,8 +349,8 @@ class Curve:
     def diffie_hellman(self, secret_scalars, public_keys_xy) -> np.ndarray:
         """elliptic_curve::ecdh::diffie_hellman for a batch: SharedSecret = x((public * secret).to_affine())
         (k256/src/ecdh.rs:41-45).  Inputs are what the reference's types guarantee: non-zero scalars, valid keys.
-        The scalars are secret: ECGPU_SECRET_SCALARS selects the constant-time variable-base kernel (csrc/varbase_ct.hpp) on
-        P-256 / P-384 and the reference schedule, constant-time as well, on secp256k1."""
+        The scalars are secret: the multiplication runs on the constant-time variable-base kernels (csrc/varbase_ct.hpp on
+        P-256 / P-384, csrc/varbase_ct_k256.hpp on secp256k1)."""
         shared, ok = self.ecdh(secret_scalars, public_keys_xy)
         if not ok.all():
             raise ValueError("diffie_hellman: element %d is not a NonZeroScalar / PublicKey pair" % int(np.argmin(ok)))

@@ -39,7 +39,7 @@ pub const ECGPU_ECDSA_LOW_S: c_uint = 2;
 /// signing only: the nonces are public, k G may use the throughput fixed-base schedule
 pub const ECGPU_PUBLIC_SCALARS: c_uint = 4;
 /// secret scalars, group element only: constant-time fixed base for k G (key generation); for a variable base (ECDH) the
-/// constant-time kernel of csrc/varbase_ct.hpp on P-256 / P-384 and the reference schedule on secp256k1
+/// constant-time kernels of csrc/varbase_ct.hpp (P-256 / P-384) and csrc/varbase_ct_k256.hpp (secp256k1)
 pub const ECGPU_SECRET_SCALARS: c_uint = 8;
 /// `ecgpu_option`: per-context tuning / test knobs (the library never reads the process environment)
 pub const ECGPU_OPT_FB_WINDOW: c_int = 0;

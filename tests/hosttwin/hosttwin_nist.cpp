@@ -149,13 +149,32 @@ static int vbct_walk(const uint8_t* scalars, const uint8_t* points, int pt_fmt, 
   free(mem);
   return 0;
 }
+#include "varbase_ct_k256.hpp"
+// secp256k1: the constant-time body with complete formulas (varbase_ct_k256.hpp), same walk
+template <int BATCH>
+static int vbct_walk_k256(const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, size_t lanes) {
+  using C = CurveK256;
+  vbct::Chunk* mem = (vbct::Chunk*)aligned_alloc(16, sizeof(vbct::Chunk) * vbct::lane_chunks<C, BATCH>() * lanes);
+  memset(mem, 0xA5, sizeof(vbct::Chunk) * vbct::lane_chunks<C, BATCH>() * lanes);
+  u32 digits[8];
+  const DigitMem dm{digits, 1};
+  for (size_t tid = 0; tid < lanes; tid++) {
+    const vbct::LaneMem ws{mem + tid, lanes};
+    for (size_t base = tid; base < n; base += lanes * BATCH)
+      vbct::lane_pass_k256<BATCH>((const u32*)scalars, (const u32*)points, pt_fmt, (u32*)out, out_fmt, out_inf, n, base, lanes, ws, dm);
+  }
+  free(mem);
+  return 0;
+}
 extern "C" int ht_vbct_mul16(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
                              size_t lanes) {
+  if (curve == 0) return vbct_walk_k256<16>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
   return curve == 1 ? vbct_walk<CurveP256, 16>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes)
                     : vbct_walk<CurveP384, 16>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
 }
 extern "C" int ht_vbct_mul(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
                            size_t lanes) {
+  if (curve == 0) return vbct_walk_k256<8>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
   return curve == 1 ? vbct_walk<CurveP256>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes)
                     : vbct_walk<CurveP384>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
 }

@@ -1,8 +1,8 @@
 """Constant-time variable base for secret scalars (ECGPU_SECRET_SCALARS with a point: ECDH), csrc/varbase_ct.hpp.
 
 P-256 / P-384 run `vbct::mul_kernel` (Jacobian doublings, masked scans of per-lane affine tables, exception-free by the
-fold k -> min(k, n - k)); secp256k1 has no dedicated kernel and takes the reference schedule (GLV + complete formulas),
-which is constant-time as well.  Every curve is compared with the C oracle at 2^20 units:
+fold k -> min(k, n - k)); secp256k1 runs `k256_mul_ct_kernel` (csrc/varbase_ct_k256.hpp: the reference's GLV split and complete
+formulas over one affine table per unit, one scan per window for both halves).  Every curve is compared with the C oracle at 2^20 units:
 with 262 144 (P-384: 196 608) resident lanes that is 4 to 6 table slots per lane, so the shared table inversion and the
 batched output run over several units; a second, ragged case adds a second pass.  Planted: zero, one, n - 1, the scalars a windowed
 Jacobian schedule without the fold would break on (n - 2, n - 6, n - 16 .. n - 1), (n +- 1) / 2, scalars >= n, identity

@@ -1,6 +1,7 @@
 """Host build of the constant-time variable-base body (csrc/varbase_ct.hpp: the kernel behind ECGPU_SECRET_SCALARS with a
 variable base, i.e. ECDH on P-256 / P-384), walked with a handful of lanes over a lane-interleaved workspace:
 
+* (P-256 / P-384: Jacobian formulas made exception-free by the fold; secp256k1: the complete formulas over affine tables)
 * k P against the big-integer model for random and edge scalars - including every scalar for which a windowed
   Jacobian schedule WITHOUT the fold k -> min(k, n - k) would meet P + P or P - P in its last addition (n - 2 for
   P-256, n - 6 for P-384, and the whole range n - 16 .. n - 1), zero, identity inputs, scalars >= n;
@@ -17,7 +18,7 @@ from oracle import ecmodel as M
 from oracle import synth
 from hosttwin_util import lib, buf, outbuf
 
-CURVES = [("p256", 1), ("p384", 2)]
+CURVES = [("p256", 1), ("p384", 2), ("k256", 0)]     # k256: csrc/varbase_ct_k256.hpp (complete formulas), the others csrc/varbase_ct.hpp
 
 
 def _vbct(cid, c, ks, ps, lanes, out_fmt=0, proj_in=False, fn="ht_vbct_mul"):
@@ -37,11 +38,16 @@ def _vbct(cid, c, ks, ps, lanes, out_fmt=0, proj_in=False, fn="ht_vbct_mul"):
     return bytes(out), bytes(inf)
 
 
+K256_LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72      # k256/src/arithmetic/mul.rs:129-152
+
+
 def edge_scalars(c):
     n = c.n
     return ([0, 1, 2, 7, 8, 9, 15, 16, 17, 0x88, 0x87, 0x89, (n - 1) // 2, (n + 1) // 2, (n + 3) // 2, (n - 3) // 2, n, n + 5,
              1 << (8 * c.nbytes - 1), (1 << (8 * c.nbytes)) - 1, int("8" * (2 * c.nbytes), 16) % n, int("7" * (2 * c.nbytes), 16) % n]
-            + [n - d for d in range(1, 18)])
+            + [n - d for d in range(1, 18)]
+            # around the GLV split of secp256k1 (harmless extra cases for the others): 2^128 +- 1, lambda (k1 = 0, k2 = 1), lambda +- 1, -lambda
+            + [(1 << 128) - 1, 1 << 128, (1 << 128) + 1, K256_LAMBDA % n, (K256_LAMBDA + 1) % n, (K256_LAMBDA - 1) % n, (n - K256_LAMBDA) % n])
 
 
 @pytest.mark.parametrize("cn,cid", CURVES)
@@ -100,6 +106,8 @@ def test_vbct_slot_counts_and_passes(cn, cid, lanes, n):
 @pytest.mark.parametrize("cn,cid", CURVES)
 @pytest.mark.parametrize("fn", ["ht_vbct_mul16", "ht_vb_mul16"])
 def test_sixteen_slots_per_pass(cn, cid, fn):
+    if cid == 0 and fn == "ht_vb_mul16":
+        pytest.skip("the public-data k256 kernel is mulfast_k256.hpp (tests/test_hosttwin_k256_fast.py)")
     """The product's pass size (16 table slots per lane and pass): 2 lanes, 53 units = one full pass and a ragged second one
     (11 and 10 slots), for the constant-time body and for the public-data body."""
     c = M.CURVES[cn]
@@ -140,6 +148,6 @@ def test_vbct_reads_the_whole_table_for_every_scalar(cn, cid):
     for k in [0, 1, c.n - 1, c.n - 2, c.n - 6, (c.n - 1) // 2, int("f" * (2 * nb), 16) % c.n, int("8" * (2 * nb), 16) % c.n,
               synth.scalar(c, 6001), synth.scalar(c, 6002)]:
         traces.append(_trace(lambda: _vbct(cid, c, [k], [P], 1)))
-    nwin = 2 * nb + 1                                   # 8 NW nibbles and the carry digit
+    nwin = 33 if cid == 0 else 2 * nb + 1               # k256: 32 nibbles of a GLV half and the carry digits (one scan serves both halves); else 8 NW nibbles and the carry digit
     assert all(t == traces[0] for t in traces)
     assert traces[0] == list(range(8)) * nwin
