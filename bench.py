@@ -581,6 +581,11 @@ def main():
                     help="fast = throughput schedule (affine result specified); ref = reference-faithful schedule (exact XYZ)")
     args = ap.parse_args()
     maybe_launch_ranks(args)
+    # Rank 0 prints ONE JSON line on stdout.  Native libraries print there too (RCCL's version banner, gloo's connection
+    # lines), so file descriptor 1 points at stderr for the duration of the run and is restored for the line itself.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -701,7 +706,10 @@ def main():
                 if r.get("table"):
                     ent["generator_table"] = r["table"]
                 line["other_configs"].append(ent)
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
     ctx.close()
