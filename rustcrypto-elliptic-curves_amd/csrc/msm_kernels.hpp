@@ -565,11 +565,22 @@ struct HeavyBucket { u32 bucket, base, chunks; };
 struct HeavyChunk { u32 bucket, index; };
 
 // the prepared point an entry names: 2 NW words in the field's internal form (16-byte loads)
+// A/B switches of the bucket sums (tools/ab_round3b.sh; DESIGN.md section 4 "MSM: round 3"):
+//   MSM_BS_WAVES     occupancy target (waves per SIMD).  3 = 150 VGPRs and no spill instead of 128 + 110 spilled: 2.5 % SLOWER.
+//   MSM_HOT_GATHER   DIAGNOSTIC ONLY (wrong sums): the term index of every gather is masked with this value, so the gathers
+//                    come from a footprint of (mask + 1) x 64 bytes per half - what the gathers cost, by the cache level they hit.
+#ifndef MSM_BS_WAVES
+#define MSM_BS_WAVES 4
+#endif
 template <class C>
 struct RawPoint { uint4 v[C::NW / 2]; };
 template <class C, int CB>
 __device__ __forceinline__ RawPoint<C> entry_point(const u32* prep, size_t n, u32 e) {
+#ifdef MSM_HOT_GATHER
+  const uint4* src = (const uint4*)(prep + ((size_t)((e >> 30) & 1u) * n + (e & (u32)MSM_HOT_GATHER)) * 2 * C::NW);
+#else
   const uint4* src = (const uint4*)(prep + ((size_t)((e >> 30) & 1u) * n + (e & Geo<CB>::INDEX_MASK)) * 2 * C::NW);
+#endif
   RawPoint<C> r;
 #pragma unroll
   for (int q = 0; q < C::NW / 2; q++) r.v[q] = src[q];
@@ -611,7 +622,7 @@ __device__ __forceinline__ void load_xyzz_as_jacobian(Jac<C>& r, const Xyzz<C>* 
 }
 
 template <class C, int CB>
-__global__ void __launch_bounds__(256, 4) bucket_sum_kernel(const u32* prep, size_t n, const u32* offsets, const u32* sorted, int nb, u32 ntask, Xyzz<C>* bucketsX,
+__global__ void __launch_bounds__(256, MSM_BS_WAVES) bucket_sum_kernel(const u32* prep, size_t n, const u32* offsets, const u32* sorted, int nb, u32 ntask, Xyzz<C>* bucketsX,
                                                             Xyzz<C>* head, Xyzz<C>* tail, u32* span_ctr, u32* span_list) {
   const u32 total = offsets[nb];
   const u32 len = task_len(total, ntask);
@@ -1049,7 +1060,7 @@ static int msm_buckets(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, 
   const size_t m = n < slab ? n : slab;                // terms of the largest slab: sizes the workspace
   // bucket-sum runs: `rounds` per lane the chip holds at that kernel's occupancy (4 workgroups of 256 per CU)
   const int rounds = (c->opt[ECGPU_OPT_MSM_ROUNDS] >= 1 && c->opt[ECGPU_OPT_MSM_ROUNDS] <= 64) ? (int)c->opt[ECGPU_OPT_MSM_ROUNDS] : MSM_ROUNDS;
-  const u32 ntask = (u32)rounds * (u32)c->num_cus * 1024u;
+  const u32 ntask = (u32)rounds * (u32)c->num_cus * 256u * MSM_BS_WAVES;
   const size_t sz_aff = (pt_fmt == FMT_PROJECTIVE) ? al(m * 8 * NW) : 0, sz_prep = al((size_t)NHALF * m * 8 * NW);
   const size_t sz_off = al((nb + 1) * 4), sz_coff = al((size_t)(NCB + 1) * 4), sz_tot = al((size_t)NCB * 4), sz_sorted = al((size_t)NDIG * m * 4 + 32);
   // level A of the sort: one 1024-thread workgroup per CU, the chunks of a window side by side
