@@ -331,59 +331,6 @@ def pmc_summary(workload, log2n, default_size):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-class SclkSampler:
-    """Shader clock while the timed steps run: the `*` line of sysfs pp_dpm_sclk every 20 ms from a thread (the timed loop
-    sits in ctypes calls, which release the GIL).  The kernels with random 64-byte gathers from beyond L2 (MSM bucket sums,
-    fixed base over the wide tables) hold ~2.1 GHz where the register-resident ones hold ~2.37 GHz (tools/clock_probe.sh,
-    profiles/r03_clock_probe.txt), so a cycle model priced at the nominal 2.4 GHz overstates what they can reach.
-    Indicative only: the guide notes that pp_dpm_sclk can read above the in-kernel clock, and runs shorter than a second
-    are sampled before the clock has settled."""
-
-    def __init__(self):
-        import glob
-        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.samples = []
-        self.stop = False
-        self.thread = None
-
-    def read(self):
-        best = None
-        for p in self.paths:
-            try:
-                for line in open(p):
-                    if "*" in line:
-                        mhz = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
-                        best = mhz if best is None else max(best, mhz)
-            except (OSError, ValueError, IndexError):
-                pass
-        return best
-
-    def __enter__(self):
-        import threading
-        if self.paths:
-            def loop():
-                while not self.stop:
-                    v = self.read()
-                    if v:
-                        self.samples.append(v)
-                    time.sleep(0.02)
-            self.thread = threading.Thread(target=loop, daemon=True)
-            self.thread.start()
-        return self
-
-    def __exit__(self, *a):
-        self.stop = True
-        if self.thread is not None:
-            self.thread.join()
-
-    def result(self):
-        if not self.samples:
-            return None
-        v = sorted(self.samples)
-        return {"sclk_mhz_median": v[len(v) // 2], "sclk_mhz_min": v[0], "sclk_mhz_max": v[-1], "samples": len(v),
-                "source": "sysfs pp_dpm_sclk every 20 ms during the timed steps (one GPU visible: the busiest card's reading)"}
-
-
 def run_workload(env, name, log2n, steps, warmup, schedule, cpu):
     """Generate inputs on the device, time `steps` passes, check parity.  env: torch, ecgpu, ctx, dev, rank, world, dist, backend."""
     import numpy as np
@@ -472,12 +419,11 @@ def run_workload(env, name, log2n, steps, warmup, schedule, cpu):
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()                        # HIP events on the launch stream bracket the same region
-    with SclkSampler() as sclk:
-        for _ in range(steps):
-            step()
-        kernel_ms = ctx.timer_stop()
-        barrier()
-        elapsed = time.perf_counter() - t0
+    for _ in range(steps):
+        step()
+    kernel_ms = ctx.timer_stop()
+    barrier()
+    elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=(dev if backend == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -555,7 +501,7 @@ def run_workload(env, name, log2n, steps, warmup, schedule, cpu):
     del d_s, d_p, d_o, d_i
     torch.cuda.empty_cache()
     return {"name": name, "n": n, "log2n": log2n, "elapsed": elapsed, "kernel_ms": kernel_ms / steps, "steps": steps, "parity": bool(parity), "checked": checked,
-            "value": world * n * steps / elapsed, "table": table, "sclk": (sclk.result() if world == 1 else None)}
+            "value": world * n * steps / elapsed, "table": table}
 
 
 def roofline_for(name, res, schedule, peak_meas, pair_meas, world=1):
@@ -591,6 +537,9 @@ def roofline_for(name, res, schedule, peak_meas, pair_meas, world=1):
                                                                                                       if pmc.get("hbm_bytes_per_launch") else None),
                    "l2_hit_rate": pmc.get("l2_hit_rate"), "valu_insts_per_launch": ctr.get("SQ_INSTS_VALU"),
                    "valu_issue_slots_pct": issue_slots, "valu_cycles_per_inst": valu_cpi, "issue_stall_frac": stall,
+                   # the clock the chip held inside the profiled kernel (GRBM_GUI_ACTIVE / 8 XCDs / the dispatch's own duration): the kernels
+                   # that gather from beyond L2 hold ~2.1 GHz, the register-resident ones ~2.36 (profiles/r03_clock_probe.txt)
+                   "effective_clock_ghz": pmc.get("effective_clock_ghz"),
                    "note": "read from the committed summary, not measured by this run"}
     alg_bytes = n * wl["bytes_per_unit"]
     r = {
@@ -602,7 +551,6 @@ def roofline_for(name, res, schedule, peak_meas, pair_meas, world=1):
         "peak_measured": peak_meas, "frac_of_peak_measured": (achieved / peak_meas if peak_meas else None),
         "mac_pair_peak_measured": pair_meas, "frac_of_mac_pair_peak": (issued / pair_meas if pair_meas else None),
         "pmc": pmc_obj,
-        "clock": res.get("sclk"),
         "hbm": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": alg_bytes / kernel_s / 1e9 / PEAK_HBM_GBS, "bytes_per_unit": wl["bytes_per_unit"]},
     }

@@ -22,14 +22,19 @@ def main():
     workload = sys.argv[4] if len(sys.argv) > 4 else None
     commit = sys.argv[5] if len(sys.argv) > 5 else None
     per = {}
+    clocks = []
     for path in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
-        acc = {}
+        acc, span = {}, {}
         with open(path) as f:
             for row in csv.DictReader(f):
                 if match not in row["Kernel_Name"]:
                     continue
                 key = (row["Counter_Name"], row["Dispatch_Id"])
                 acc[key] = acc.get(key, 0.0) + float(row["Counter_Value"])
+                # effective clock of THIS dispatch in THIS pass: the counter sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+                if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and row.get("End_Timestamp") and float(row["End_Timestamp"]) > float(row["Start_Timestamp"]):
+                    span[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+        clocks += [acc[("GRBM_GUI_ACTIVE", d)] / 8.0 / ns for d, ns in span.items()]
         names = {k[0] for k in acc}
         for nm in names:
             vals = [v for (c, _), v in acc.items() if c == nm]
@@ -56,6 +61,8 @@ def main():
                                         "rule": "raw" if abs(f / known_read - 1) < abs(2 * f / known_read - 1) else "x2"}
             if res["fetch_calibration"]["rule"] == "x2":
                 res["hbm_bytes_per_launch"] = x2
+    if clocks:
+        res["effective_clock_ghz"] = sum(clocks) / len(clocks)
     if "TCC_HIT_sum" in per:
         res["l2_hit_rate"] = per["TCC_HIT_sum"] / max(1.0, per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
     print(json.dumps(res, indent=1))
