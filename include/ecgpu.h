@@ -106,8 +106,9 @@ enum {
    * over all eight entries of a per-lane affine table, Jacobian doublings and a mixed addition for every digit whose two special
    * operands (empty accumulator, zero digit) are resolved by masks; the fold keeps every addition off the formula's exceptional
    * cases for every k (the file has the argument) - 1.8x / 1.9x the reference schedule.  secp256k1 (csrc/varbase_ct_k256.hpp): the
-   * reference's GLV split and COMPLETE formulas, over one per-lane affine table (one masked scan per window serves both halves,
-   * beta x multiplied in) with shared inversions - 1.28x the reference schedule.
+   * reference's GLV split and recoding on Jacobian formulas over one per-lane common-Z table (one masked scan per window serves both
+   * halves, beta x multiplied in); the bounds of the split keep every addition off the exceptional cases (the file has the
+   * argument: the accumulator's two coordinates stay below the GLV lattice's shortest vector) - 1.5x the reference schedule.
    * Staged host copies of the scalars are cleared as with ECGPU_EXACT_REFERENCE. */
   ECGPU_SECRET_SCALARS = 8u
 };

@@ -35,8 +35,8 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
   HIPCHK(c, hipGetLastError());
   return 1;
 }
-// secret scalars on a variable base (ECDH): varbase_ct_k256.hpp - complete formulas over per-lane AFFINE tables, one masked scan per
-// window for both GLV halves, shared inversions; K256_CT_BATCH units per lane and pass
+// secret scalars on a variable base (ECDH): varbase_ct_k256.hpp - GLV, Jacobian formulas (exception-free on this loop's operands) over a
+// per-lane common-Z table, one masked scan per window for both halves; K256_CT_BATCH results per lane share the output inversion
 #ifndef K256_CT_BATCH
 #define K256_CT_BATCH 16
 #endif
@@ -46,7 +46,7 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
 template <int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k256_mul_ct_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf,
                                                                  size_t n, vbct::Chunk* ws_all) {
-  const vbct::LaneMem ws{ws_all + (size_t)blockIdx.x * vbct::lane_chunks<CurveK256, BATCH>() * 256 + threadIdx.x, 256};
+  const vbct::LaneMem ws{ws_all + (size_t)blockIdx.x * vbct::k256_lane_chunks<BATCH>() * 256 + threadIdx.x, 256};
   __shared__ u32 lds_digits[8][256];
   const DigitMem dm{&lds_digits[0][threadIdx.x], 256};
   const size_t T = (size_t)gridDim.x * blockDim.x;
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256, WAVES) k256_mul_ct_kernel(const u32* scal
 template <>
 int CurveOps<CurveK256>::mul_ct(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
   const dim3 grid(ecgpu_grid_for(c, n, K256_CT_WAVES));
-  const size_t ws_need = (size_t)grid.x * 256 * vbct::lane_chunks<CurveK256, K256_CT_BATCH>() * sizeof(vbct::Chunk);
+  const size_t ws_need = (size_t)grid.x * 256 * vbct::k256_lane_chunks<K256_CT_BATCH>() * sizeof(vbct::Chunk);
   if (ws_need > c->tab_ws_cap) {
     if (c->tab_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->tab_ws)); c->tab_ws = nullptr; c->tab_ws_cap = 0; }
     HIPCHK(c, hipMalloc(&c->tab_ws, ws_need));

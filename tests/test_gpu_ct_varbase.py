@@ -1,8 +1,8 @@
 """Constant-time variable base for secret scalars (ECGPU_SECRET_SCALARS with a point: ECDH), csrc/varbase_ct.hpp.
 
 P-256 / P-384 run `vbct::mul_kernel` (Jacobian doublings, masked scans of per-lane affine tables, exception-free by the
-fold k -> min(k, n - k)); secp256k1 runs `k256_mul_ct_kernel` (csrc/varbase_ct_k256.hpp: the reference's GLV split and complete
-formulas over one affine table per unit, one scan per window for both halves).  Every curve is compared with the C oracle at 2^20 units:
+fold k -> min(k, n - k)); secp256k1 runs `k256_mul_ct_kernel` (csrc/varbase_ct_k256.hpp: the reference's GLV split, Jacobian
+formulas over one common-Z table per unit - exception-free by the bounds of the split -, one scan per window for both halves).  Every curve is compared with the C oracle at 2^20 units:
 with 262 144 (P-384: 196 608) resident lanes that is 4 to 6 table slots per lane, so the shared table inversion and the
 batched output run over several units; a second, ragged case adds a second pass.  Planted: zero, one, n - 1, the scalars a windowed
 Jacobian schedule without the fold would break on (n - 2, n - 6, n - 16 .. n - 1), (n +- 1) / 2, scalars >= n, identity
@@ -22,8 +22,19 @@ ORDER = {0: synth.M.K256.n, 1: synth.M.P256.n, 2: synth.M.P384.n}
 
 
 def _edge_values(n_ord, nb):
-    return ([0, 1, 2, 8, 9, 16, (n_ord - 1) // 2, (n_ord + 1) // 2, n_ord + 3, (1 << (8 * nb)) - 1, int("8" * (2 * nb), 16) % n_ord]
+    vals = ([0, 1, 2, 8, 9, 16, (n_ord - 1) // 2, (n_ord + 1) // 2, n_ord + 3, (1 << (8 * nb)) - 1, int("8" * (2 * nb), 16) % n_ord]
             + [n_ord - d for d in range(1, 18)])
+    if n_ord == synth.M.K256.n:
+        # secp256k1 (csrc/varbase_ct_k256.hpp): small multiples of both GLV halves, and scalars whose split lands next to the corners of
+        # the fundamental cell, where |k1|, |k2| reach their bounds - the operands closest to the lattice's shortest vector
+        lam = synth.M.K256_LAMBDA
+        a1, a2, b1 = 0x3086D221A7D46BCDE86C90E49284EB15, 0x114CA50F7A8E2F3F657C1108D9D44CFD8, -0xE4437ED6010E88286F547FA90ABFE4C3
+        vals += [(d + e * lam) % n_ord for d in (0, 1, 8, 16, n_ord - 1, n_ord - 8) for e in (1, 8, 17, n_ord - 1)]
+        for s1 in (-1, 1):
+            for s2 in (-1, 1):
+                x, y = (s1 * a1 + s2 * a2) // 2, (s1 * b1 + s2 * a1) // 2
+                vals += [(x + d + y * lam) % n_ord for d in (-1, 0, 1)] + [(x + (y + d) * lam) % n_ord for d in (-1, 1)]
+    return vals
 
 
 def _run(cname, cid, n, first, sample_all):

@@ -1,7 +1,7 @@
 """Host build of the constant-time variable-base body (csrc/varbase_ct.hpp: the kernel behind ECGPU_SECRET_SCALARS with a
 variable base, i.e. ECDH on P-256 / P-384), walked with a handful of lanes over a lane-interleaved workspace:
 
-* (P-256 / P-384: Jacobian formulas made exception-free by the fold; secp256k1: the complete formulas over affine tables)
+* (P-256 / P-384: Jacobian formulas made exception-free by the fold; secp256k1: Jacobian formulas, exception-free by the bounds of the GLV split)
 * k P against the big-integer model for random and edge scalars - including every scalar for which a windowed
   Jacobian schedule WITHOUT the fold k -> min(k, n - k) would meet P + P or P - P in its last addition (n - 2 for
   P-256, n - 6 for P-384, and the whole range n - 16 .. n - 1), zero, identity inputs, scalars >= n;
@@ -18,7 +18,7 @@ from oracle import ecmodel as M
 from oracle import synth
 from hosttwin_util import lib, buf, outbuf
 
-CURVES = [("p256", 1), ("p384", 2), ("k256", 0)]     # k256: csrc/varbase_ct_k256.hpp (complete formulas), the others csrc/varbase_ct.hpp
+CURVES = [("p256", 1), ("p384", 2), ("k256", 0)]     # k256: csrc/varbase_ct_k256.hpp (GLV + Jacobian, lattice argument), the others csrc/varbase_ct.hpp
 
 
 def _vbct(cid, c, ks, ps, lanes, out_fmt=0, proj_in=False, fn="ht_vbct_mul"):
@@ -47,7 +47,33 @@ def edge_scalars(c):
              1 << (8 * c.nbytes - 1), (1 << (8 * c.nbytes)) - 1, int("8" * (2 * c.nbytes), 16) % n, int("7" * (2 * c.nbytes), 16) % n]
             + [n - d for d in range(1, 18)]
             # around the GLV split of secp256k1 (harmless extra cases for the others): 2^128 +- 1, lambda (k1 = 0, k2 = 1), lambda +- 1, -lambda
-            + [(1 << 128) - 1, 1 << 128, (1 << 128) + 1, K256_LAMBDA % n, (K256_LAMBDA + 1) % n, (K256_LAMBDA - 1) % n, (n - K256_LAMBDA) % n])
+            + [(1 << 128) - 1, 1 << 128, (1 << 128) + 1, K256_LAMBDA % n, (K256_LAMBDA + 1) % n, (K256_LAMBDA - 1) % n, (n - K256_LAMBDA) % n]
+            # small multiples of both halves and their sums (prefixes (d, 0), (0, e), (d, e): where an incomplete addition would meet +-Q first)
+            + [(d + e * K256_LAMBDA) % n for d in (0, 1, 2, 8, 15, 16, 17, n - 1, n - 8, n - 16) for e in (1, 2, 8, 16, 17, n - 1, n - 8)])
+
+
+def k256_corner_scalars():
+    """Scalars whose GLV split lands next to the corners of the fundamental cell, where |k1| and |k2| reach their bounds
+    (tests/test_oracle_golden.py::test_k256_glv_bounds): the operands closest to the lattice's shortest vector."""
+    n, lam = M.K256.n, K256_LAMBDA
+    a1, a2, b1 = 0x3086D221A7D46BCDE86C90E49284EB15, 0x114CA50F7A8E2F3F657C1108D9D44CFD8, -0xE4437ED6010E88286F547FA90ABFE4C3
+    out = []
+    for s1 in (-1, 1):
+        for s2 in (-1, 1):
+            x, y = (s1 * a1 + s2 * a2) // 2, (s1 * b1 + s2 * a1) // 2
+            out += [(x + d + y * lam) % n for d in (-9, -1, 0, 1, 2, 8)] + [(x + (y + d) * lam) % n for d in (-8, -1, 1, 7)]
+    return out
+
+
+def test_vbct_k256_corner_scalars():
+    c = M.CURVES["k256"]
+    nb = c.nbytes
+    ks = k256_corner_scalars()
+    ps = [synth.point(c, 4300 + (i % 3)) for i in range(len(ks))]
+    out, inf = _vbct(0, c, ks, ps, 3, fn="ht_vbct_mul16")
+    for i, k in enumerate(ks):
+        want = M.affine_mul(c, k % c.n, ps[i])
+        assert out[2 * nb * i:2 * nb * (i + 1)] == M.i2b(c, want[0]) + M.i2b(c, want[1]) and inf[i] == 0, (i, hex(k))
 
 
 @pytest.mark.parametrize("cn,cid", CURVES)

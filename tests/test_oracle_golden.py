@@ -131,6 +131,49 @@ def test_k256_glv_and_radix16():
     assert all(-8 <= x <= 7 for x in d[:64]) and 0 <= d[64] <= 1
 
 
+
+# the reduced basis of the GLV lattice {(x, y): x + y lambda = 0 mod n} (k256/src/arithmetic/mul.rs:129-152: a1, b1, a2, b2 = a1)
+K256_A1 = 0x3086D221A7D46BCDE86C90E49284EB15
+K256_A2 = 0x114CA50F7A8E2F3F657C1108D9D44CFD8
+
+
+def k256_glv_corner_scalars():
+    """Scalars whose split lands next to the corners of the fundamental cell (|alpha|, |beta| -> 1/2), where |k1|, |k2| peak."""
+    n, lam = M.K256.n, M.K256_LAMBDA
+    b1, b2 = -M.K256_MINUS_B1, K256_A1
+    out = []
+    for s1 in (-1, 1):
+        for s2 in (-1, 1):
+            x, y = (s1 * K256_A1 + s2 * K256_A2) // 2, (s1 * b1 + s2 * b2) // 2
+            for d in range(-40, 41):
+                out.append((x + d + y * lam) % n)
+                out.append((x + (y + d) * lam) % n)
+    return out
+
+
+def test_k256_glv_bounds():
+    """The facts csrc/varbase_ct_k256.hpp's exception-freeness argument stands on: the GLV lattice's shortest non-zero vector in the
+    maximum norm is |b1| = 2^127.835, and decompose_scalar stays below (a1 + a2 + 1) / 2 and (b2 - b1) / 2 + 1 (libsecp256k1's bounds),
+    i.e. more than 2^126 below it - also next to the corners of the fundamental cell."""
+    n, lam = M.K256.n, M.K256_LAMBDA
+    a1, a2, b1, b2 = K256_A1, K256_A2, -M.K256_MINUS_B1, K256_A1
+    assert (a1 + b1 * lam) % n == 0 and (a2 + b2 * lam) % n == 0 and a1 * b2 - a2 * b1 == n          # a basis of the lattice
+    mu = min(max(abs(i * a1 + j * a2), abs(i * b1 + j * b2)) for i in range(-8, 9) for j in range(-8, 9) if (i, j) != (0, 0))
+    assert mu == M.K256_MINUS_B1 == 0xE4437ED6010E88286F547FA90ABFE4C3
+    bound1, bound2 = (a1 + a2 + 1) // 2, (b2 - b1) // 2 + 1
+    assert max(bound1, bound2) + 16 < mu - (1 << 126)
+    rng = random.Random(20261004)
+    ks = k256_glv_corner_scalars() + [rng.randrange(n) for _ in range(20000)] + list(range(64)) + [n - d for d in range(1, 64)]
+    top1 = top2 = 0
+    for k in ks:
+        r1, r2 = M.k256_decompose_scalar(k)
+        assert (r1 + r2 * lam - k) % n == 0
+        k1 = r1 if not M.k256_is_high(r1) else n - r1
+        k2 = r2 if not M.k256_is_high(r2) else n - r2
+        top1, top2 = max(top1, k1), max(top2, k2)
+    assert top1 < bound1 and top2 < bound2
+    assert top1 > bound1 - 64 and top2 > bound2 - 64          # the corner scalars do reach the bounds
+
 @pytest.mark.parametrize("cn", CURVES)
 def test_faithful_equals_independent_random(cn):
     """test_lincomb / test_mul_by_generator / test_lincomb_slice (mul.rs:493-526) restated."""
