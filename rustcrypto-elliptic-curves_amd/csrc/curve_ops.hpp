@@ -16,6 +16,13 @@
 #define FB_BATCH (C::NW > 8 ? 16 : 64)
 #endif
 
+// occupancy target (waves per SIMD) of the constant-time fixed-base kernel fb::mul_ct_kernel.  With the Jacobian addition (fixedbase_ct.hpp)
+// the live set fits 128 VGPRs on the 8-word curves (k256: 10 spilled) and 168 on P-384 (15 spilled); signing per 2^20 at these against the
+// round-2 targets 3 / 4 / 2: k256 4.66 vs 4.72 ms, p384 16.4 vs 17.1 ms (profiles/r03_ab_measurements.txt)
+#ifndef FBCT_WAVES
+#define FBCT_WAVES(C) (C::NW > 8 ? 3 : 4)
+#endif
+
 namespace ecgpu {
 
 template <class C>
@@ -177,7 +184,7 @@ struct CurveOps {
     int rc = ensure_fb_wide_table<fb::CT_WB>(c, &c->fbct_table[C::ID]);
     if (rc == FB_NOMEM) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "out of device memory for the 5-bit generator table");
     if (rc) return rc;
-    constexpr int WAVES = C::NW > 8 ? 2 : (C::ID == 0 ? 3 : 4);       // what the complete addition's live set allows: 230 / 146 / 127 VGPRs
+    constexpr int WAVES = FBCT_WAVES(C);
     hipLaunchKernelGGL((fb::mul_ct_kernel<C, 8, WAVES>), dim3(ecgpu_grid_for(c, n, WAVES)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)c->fbct_table[C::ID], out,
                        out_fmt, out_inf, n);
     HIPCHK(c, hipGetLastError());

@@ -237,10 +237,11 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
 //     256-bit curve: 53 KB, the wide-table builder with WB = 5);
 //   * EVERY entry of window j is read (the address depends on j and the entry number only - one broadcast load for the
 //     whole wave) and the digit's one is kept by masks, like LookupTable::select (k256 mul.rs:92-127);
-//   * the reference's complete mixed addition (Renes-Costello-Batina, no exceptional case; a zero digit is the
-//     `infinity` flag of the addend, a mask again), the sign of the digit is a masked negation;
+//   * ONE Jacobian mixed addition per window, executed for every digit; a zero digit and an empty accumulator are resolved by
+//     masks afterwards, and the bounds on the digits keep the formula off its exceptional cases (argument in
+//     fixedbase_ct.hpp; round 2 had the reference's complete mixed addition here); the sign of the digit is a masked negation;
 //   * one inversion per BATCH results (Montgomery's trick on the homogeneous Z; a zero Z is masked to 1 and flagged).
-// 52 (77) complete additions instead of the reference schedule's 256 (384) doublings and 64 (96) additions.
+// 52 (77) additions of 8M + 3S instead of the reference schedule's 256 (384) doublings and 64 (96) additions.
 // ---------------------------------------------------------------------------------------------------------------------
 template <class C, int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) mul_ct_kernel(const u32* scalars, const AffEntry<C>* table, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {

@@ -2,6 +2,7 @@
 // table entries it reads).  See fixedbase.hpp (mul_ct_kernel) for the schedule and its place in the library.
 #pragma once
 #include "jacobian.hpp"
+#include "varbase_ct.hpp"        // add_mixed_raw, fe_mask_select
 
 namespace ecgpu {
 namespace fb {
@@ -10,18 +11,37 @@ constexpr int CT_WB = 5;                                        // signed 5-bit 
 constexpr int CT_ENTRIES = 1 << (CT_WB - 1);                    // T[j][d-1] = d 2^(5j) G, d = 1..16
 template <class C> constexpr int ct_nwin() { return (8 * C::NB + CT_WB - 1) / CT_WB; }
 
-// acc = k G for a scalar k < n (reduced by the caller), in the reference's homogeneous projective coordinates.
+// acc = k G for a scalar k < n (reduced by the caller), returned in the reference's homogeneous projective coordinates.
 // Nothing but data depends on k: the digits come from branch-free recoding, EVERY entry of window j is read (the
 // address depends on j and the entry number only) and the digit's one is kept by AND / OR masks - arithmetic masks, not
 // selects: a select of a loaded value lets the compiler load only under the condition, and it did (the VMEM instruction
-// count followed the digits until this was an AND / OR) -, the sign is a masked negation, a zero digit the addend's
-// infinity flag, the addition the reference's complete mixed addition.
+// count followed the digits until this was an AND / OR) -, the sign is a masked negation.
+//
+// The addition is the plain Jacobian mixed addition (8M + 3S), executed for EVERY digit and resolved by masks for a zero
+// digit (the accumulator is kept) and an empty accumulator (the result is the entry itself).  Round 2 used the reference's
+// complete mixed addition here (11M + 2 multiplications by b + 29 field additions on the a = -3 curves); the Jacobian
+// one is exception-free on the operands this loop meets.  Let S_j = sum_{i < j} d_i 32^i, so the accumulator is S_j G when
+// Q = d_j 32^j G is added; -16 <= d_i <= 16 gives |S_j| <= 16 (32^j - 1) / 31 < 0.52 * 32^j, and S_NWIN = k in [0, n).
+//   acc = O   iff n | S_j iff S_j = 0 (|S_j| < 32^j < n) iff all lower digits are zero (at the highest non-zero one,
+//             |S_i| < 32^i <= |d_i| 32^i contradicts S_(i+1) = 0): the `empty` mask, updated from the digits, no test of Z;
+//   acc = -Q  iff n | S_(j+1): S_(j+1) = 0 as an integer (it is k < n after the top window, smaller than n before), which
+//             the same contradiction excludes for d_j != 0;
+//   acc = +Q  iff n | D, D = S_j - d_j 32^j.  D != 0 since |S_j| < 32^j <= |d_j| 32^j.  Below the top window
+//             |D| < 17 * 32^(NWIN-2) < n.  In the top window (0 <= d <= 16, 32^j = 2^(5 (NWIN-1))) |D| < 2n and D = 2 S_j - k,
+//             so D = -n needs S_j < 0 and n = d 32^j + |S_j|, i.e. |S_j| = n mod 32^j: 2^255 (1 - 2^-128) for secp256k1,
+//             2^255 (1 - 2^-32) for P-256, 2^380 (1 - 2^-252) for P-384 - all above the 0.52 * 32^j that bounds |S_j|
+//             (tests/test_oracle_golden.py::test_fixed_base_ct_top_window checks the three moduli).
+// So the only special operands are the empty accumulator and a zero digit, both masks.
 template <class C>
-ECGPU_HD void mul_ct_one(typename C::Pt& acc, const u32* k, const AffEntry<C>* table) {
+ECGPU_HD void mul_ct_one(typename C::Pt& out, const u32* k, const AffEntry<C>* table) {
   constexpr int NW = C::NW, NWIN = ct_nwin<C>();
   static_assert((8 * C::NB) % CT_WB != 0, "the top window must have room for the last carry");
   using Fe = typename C::Fe;
-  C::pt_identity(acc);
+  Fe one;
+  C::fe_one(one);
+  Jac<C> acc;
+  C::fe_zero(acc.x); C::fe_zero(acc.y); C::fe_zero(acc.z);
+  u32 empty = 0xFFFFFFFFu;                                        // all ones while every digit so far was zero
   u32 carry = 0;
 #pragma unroll 1
   for (int j = 0; j < NWIN; j++) {
@@ -34,9 +54,9 @@ ECGPU_HD void mul_ct_one(typename C::Pt& acc, const u32* k, const AffEntry<C>* t
     carry = (j == NWIN - 1) ? 0u : ((v + (1u << (CT_WB - 1))) >> CT_WB);         // v >= 16 -> v - 32 and a carry; the top window keeps v
     const int d = (int)v - (int)(carry << CT_WB);                                // -16 .. 16
     const u32 sgn = (u32)(d >> 31), mag = ((u32)d ^ sgn) - sgn;                  // |d| without a branch
-    typename C::Af q;
-    C::fe_zero(q.x);
-    C::fe_zero(q.y);
+    Fe qx, qy;
+    C::fe_zero(qx);
+    C::fe_zero(qy);
     const AffEntry<C>* row = table + (size_t)j * CT_ENTRIES;
 #pragma unroll 4
     for (int e = 0; e < CT_ENTRIES; e++) {
@@ -44,16 +64,29 @@ ECGPU_HD void mul_ct_one(typename C::Pt& acc, const u32* k, const AffEntry<C>* t
       const u32 mk = 0u - (((mag ^ (u32)(e + 1)) - 1u) >> 31);                   // all ones iff mag == e + 1
       const AffEntry<C> t = row[e];
 #pragma unroll
-      for (int w = 0; w < NW; w++) { q.x.v[w] |= t.x.v[w] & mk; q.y.v[w] |= t.y.v[w] & mk; }
+      for (int w = 0; w < NW; w++) { qx.v[w] |= t.x.v[w] & mk; qy.v[w] |= t.y.v[w] & mk; }
     }
     Fe ny;
-    C::fe_neg(ny, q.y);
-    C::fe_select(q.y, sgn != 0, ny, q.y);
-    q.inf = (mag == 0) ? 1u : 0u;
-    typename C::Pt t;
-    C::pt_add_mixed(t, acc, q);
-    acc = t;
+    C::fe_neg(ny, qy);
+    vbct::fe_mask_select<C>(qy, sgn, ny, qy);
+    const u32 zd = 0u - ((mag - 1u) >> 31);                                      // all ones iff the digit is zero
+    Jac<C> t = acc;
+    vbct::add_mixed_raw<C>(t, qx, qy);                                           // garbage for an empty accumulator or a zero digit
+    const u32 take_q = empty & ~zd;                                              // first non-zero digit: the entry itself
+    vbct::fe_mask_select<C>(t.x, take_q, qx, t.x);
+    vbct::fe_mask_select<C>(t.y, take_q, qy, t.y);
+    vbct::fe_mask_select<C>(t.z, take_q, one, t.z);
+    vbct::fe_mask_select<C>(acc.x, zd, acc.x, t.x);
+    vbct::fe_mask_select<C>(acc.y, zd, acc.y, t.y);
+    vbct::fe_mask_select<C>(acc.z, zd, acc.z, t.z);
+    empty &= zd;
   }
+  // Jacobian (X, Y, Z) = homogeneous (X Z : Y : Z^3); k = 0: the identity (0 : 1 : 0)
+  Fe zz;
+  C::fe_sqr(zz, acc.z);
+  C::fe_mul(out.x, acc.x, acc.z);
+  C::fe_mul(out.z, zz, acc.z);
+  vbct::fe_mask_select<C>(out.y, empty, one, acc.y);
 }
 
 }  // namespace fb

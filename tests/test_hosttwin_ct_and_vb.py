@@ -194,6 +194,15 @@ def test_constant_time_fixed_base_reads_the_whole_table(cn, cid):
     table = b"".join(rows)
     scalars = [0, 1, 2, 15, 16, 17, 31, 32, 33, c.n - 1, c.n - 2, c.n - 16, c.n - 17, c.n // 2, c.n // 2 + 1, int("f" * (2 * nb - 1), 16),
                int("8" * (2 * nb), 16) % c.n, (1 << (8 * nb - 1)), c.n, c.n + 5] + [synth.scalar(c, 900 + i) for i in range(6)]
+    # the operands closest to an exceptional case of the Jacobian addition (csrc/fixedbase_ct.hpp): the largest top digits with the most
+    # negative lower part, every digit at +-16, the scalar n - 2 (n mod 32^(nwin-1)) that would make the last addition a doubling if the
+    # bound on the lower digits did not exclude it, single digits d 32^j and d 32^j +- 1
+    top = 32 ** (nwin - 1)
+    r = c.n % top
+    scalars += [(c.n - 2 * r) % c.n, (c.n - 2 * r + 1) % c.n, (c.n // top) * top, (c.n // top) * top - 1, top - 1, top, top + 1, 2 * top - 1,
+                sum(16 * 32 ** i for i in range(nwin - 1)) % c.n, (top - sum(16 * 32 ** i for i in range(nwin - 1))) % c.n,
+                sum(15 * 32 ** i for i in range(0, nwin - 1, 2)) % c.n]
+    scalars += [d * 32 ** j + e for j in (1, 7, nwin - 2) for d in (1, 16, 17, 31) for e in (-1, 0, 1)]
     L = lib()
     L.ht_mul_ct.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     traces = []

@@ -151,6 +151,22 @@ def k256_glv_corner_scalars():
     return out
 
 
+@pytest.mark.parametrize("cn", ["k256", "p256", "p384"])
+def test_fixed_base_ct_top_window(cn):
+    """The numeric facts csrc/fixedbase_ct.hpp's exception-freeness argument uses: signed 5-bit digits, S_j = the value of the digits
+    below window j, |S_j| <= 16 (32^j - 1) / 31.  Below the top window 17 * 32^j < n; in the top window the one candidate D = -n
+    needs |S_j| = n mod 32^j, which is larger than the bound on |S_j|; and |D| < 2n there."""
+    c = M.CURVES[cn]
+    nwin = (8 * c.nbytes + 4) // 5
+    assert (8 * c.nbytes) % 5 != 0
+    top = 32 ** (nwin - 1)
+    bound = 16 * (top - 1) // 31
+    assert 17 * 32 ** (nwin - 2) < c.n
+    assert top < c.n and c.n % top > bound
+    dmax = ((c.n - 1) >> (5 * (nwin - 1))) + 1            # the top window keeps its value: the scalar's top bits plus a carry
+    assert dmax <= 16 and bound + dmax * top < 2 * c.n
+
+
 def test_k256_glv_bounds():
     """The facts csrc/varbase_ct_k256.hpp's exception-freeness argument stands on: the GLV lattice's shortest non-zero vector in the
     maximum norm is |b1| = 2^127.835, and decompose_scalar stays below (a1 + a2 + 1) / 2 and (b2 - b1) / 2 + 1 (libsecp256k1's bounds),
