@@ -113,6 +113,30 @@ ECGPU_HD void add_mixed(Jac<C>& p, const typename C::Fe& x2, const typename C::F
   C::fe_sub(p.y, t, h);
 }
 
+// In-place p += (x2, y2) for p = (X1, Y1, 1) AFFINE and finite (the caller knows: the first addition after a set), (x2, y2) affine
+// and not the identity: 4M + 2S, the mixed addition with Z1 = 1.  Same special cases by control flow.
+template <class C>
+ECGPU_HD void add_affine(Jac<C>& p, const typename C::Fe& x2, const typename C::Fe& y2) {
+  using Fe = typename C::Fe;
+  Fe h, r, t, u;
+  C::fe_sub(h, x2, p.x);
+  C::fe_sub(r, y2, p.y);
+  if (__builtin_expect(C::fe_is_zero_fast(h), 0)) {
+    if (C::fe_is_zero(r)) dbl<C>(p);      // same point (Z = 1 already)
+    else set_infinity<C>(p);              // opposite points
+    return;
+  }
+  p.z = h;
+  C::fe_sqr(t, h);
+  C::fe_mul(h, t, h);
+  C::fe_mul(t, p.x, t);
+  C::fe_sqr(u, r);
+  C::fe_sub(u, u, h); C::fe_sub(u, u, t); C::fe_sub(p.x, u, t);
+  C::fe_sub(t, t, p.x); C::fe_mul(t, r, t);
+  C::fe_mul(h, p.y, h);
+  C::fe_sub(p.y, t, h);
+}
+
 // general addition r = p + q (11M + 5S), all special cases handled
 template <class C>
 ECGPU_HD void add(Jac<C>& r, const Jac<C>& p, const Jac<C>& q) {

@@ -79,13 +79,14 @@ int ht_nist_mul_ref(int curve, const uint8_t* pts, const uint8_t* ks, uint8_t* o
 #include "jacobian.hpp"
 template <class C> static void load_jac(Jac<C>& p, const uint8_t* b) { load<C>(p.x, b); load<C>(p.y, b + C::NB); load<C>(p.z, b + 2 * C::NB); }
 template <class C> static void store_jac(uint8_t* b, const Jac<C>& p) { store<C>(b, p.x); store<C>(b + C::NB, p.y); store<C>(b + 2 * C::NB, p.z); }
-// op: 0 dbl, 1 add_mixed (q = x||y), 2 add (q Jacobian)
+// op: 0 dbl, 1 add_mixed (q = x||y), 2 add (q Jacobian), 3 add_affine (p = (x, y, 1), q = x||y)
 template <class C>
 static int jac_op(int op, const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {
   for (int i = 0; i < n; i++) {
     Jac<C> a, b, r; load_jac<C>(a, p + 3 * C::NB * i);
     if (op == 0) { r = a; jac::dbl<C>(r); }
     else if (op == 1) { typename C::Fe x, y; load<C>(x, q + 2 * C::NB * i); load<C>(y, q + 2 * C::NB * i + C::NB); r = a; jac::add_mixed<C>(r, x, y); }
+    else if (op == 3) { typename C::Fe x, y; load<C>(x, q + 2 * C::NB * i); load<C>(y, q + 2 * C::NB * i + C::NB); r = a; jac::add_affine<C>(r, x, y); }
     else { load_jac<C>(b, q + 3 * C::NB * i); jac::add<C>(r, a, b); }
     store_jac<C>(out + 3 * C::NB * i, r);
   }

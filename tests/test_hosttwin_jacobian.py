@@ -49,6 +49,15 @@ def test_jacobian_ops(cn, cid):
     o = bytes(out)
     for i, (a, b) in enumerate(pairs):
         assert back(o, i) == M.affine_add(c, a, b), ("add_mixed", i)
+    # add_affine: the accumulator is (x, y, 1) - the fixed-base kernel's second entry; same point and opposite points included
+    pairs_a = [(a, b) for a, b in pairs if a is not None]
+    jin = b"".join(fe(a[0]) + fe(a[1]) + fe(1) for a, _ in pairs_a)
+    qin = b"".join(fe(b[0]) + fe(b[1]) for _, b in pairs_a)
+    out = outbuf(3 * nb * len(pairs_a))
+    assert lib().ht_jac_op(cid, 3, buf(jin), buf(qin), out, len(pairs_a)) == 0
+    o = bytes(out)
+    for i, (a, b) in enumerate(pairs_a):
+        assert back(o, i) == M.affine_add(c, a, b), ("add_affine", i)
     pairs2 = pairs + [(pts[3], None), (None, None)]
     jin = b"".join(b"".join(fe(v) for v in jacp(a)) for a, _ in pairs2)
     qin = b"".join(b"".join(fe(v) for v in jacp(b)) for _, b in pairs2)
