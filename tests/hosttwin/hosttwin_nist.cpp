@@ -154,7 +154,6 @@ static int vbct_walk(const uint8_t* scalars, const uint8_t* points, int pt_fmt, 
 // secp256k1: the constant-time body (GLV, Jacobian formulas over a common-Z table: varbase_ct_k256.hpp), same walk
 template <int BATCH>
 static int vbct_walk_k256(const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, size_t lanes) {
-  using C = CurveK256;
   vbct::Chunk* mem = (vbct::Chunk*)aligned_alloc(16, sizeof(vbct::Chunk) * vbct::k256_lane_chunks<BATCH>() * lanes);
   memset(mem, 0xA5, sizeof(vbct::Chunk) * vbct::k256_lane_chunks<BATCH>() * lanes);
   u32 digits[8];
