@@ -393,7 +393,7 @@ struct CurveOps {
     if (rc) return rc;
     u32* r_xy = (u32*)c->ecdsa_ws;
     uint8_t* r_inf = (uint8_t*)c->ecdsa_ws + sz_p;
-    // The nonce is secret: k G runs on the constant-time fixed-base kernel (complete formulas, every table entry read,
+    // The nonce is secret: k G runs on the constant-time fixed-base kernel (every table entry read, one masked addition per window,
     // no digit-dependent branch or address) - or, with ECGPU_EXACT_REFERENCE, on the reference's own mul_by_generator
     // schedule, which is constant-time as well - unless the caller declares the scalars public.
     if (flags & ECGPU_PUBLIC_SCALARS) rc = lincomb(c, k, nullptr, FMT_AFFINE, 1, r_xy, FMT_AFFINE, r_inf, n, 0u);

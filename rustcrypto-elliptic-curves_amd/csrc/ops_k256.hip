@@ -41,7 +41,7 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
 #define K256_CT_BATCH 16
 #endif
 #ifndef K256_CT_WAVES
-#define K256_CT_WAVES 3        // 168 VGPRs: 47.8 ms per 2^22 against 49.6 ms at 4 waves per SIMD (128 VGPRs, 114 spilled) and 49.5 ms at 2
+#define K256_CT_WAVES 3        // 168 VGPRs, 26 spilled: 39.6 ms per 2^22 against 41.5 ms at 4 waves per SIMD (128 VGPRs, 82 spilled); 32 results per pass: no difference
 #endif
 template <int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k256_mul_ct_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf,
