@@ -14,6 +14,7 @@
 #include "jacobian.hpp"
 #include "fixedbase_ct.hpp"
 #include "kernels.hpp"
+#include "msm.hpp"                // XYZZ accumulators (8M + 2S per mixed addition)
 
 namespace ecgpu {
 namespace fb {
@@ -67,11 +68,59 @@ __global__ void __launch_bounds__(256) table_affine_kernel(const Jac<C>* tmp, Af
   C::fe_mul(table[e].y, tmp[e].y, t);
 }
 
+// The cnt XYZZ results of one lane (element j is global index base + j * stride) to affine with ONE inversion: with
+// w = ZZ ZZZ, 1 / ZZ = ZZZ / w and 1 / ZZZ = ZZ / w (8M per result and a share of the inversion; the Jacobian epilogue,
+// jac::store_batch_affine, takes 6M + 1S - the one multiplication more is paid once per result, the squaring the XYZZ
+// addition saves is saved once per addition).  Same output formats as jac::store_batch_affine.
+template <class C>
+ECGPU_HD void store_batch_affine_xyzz(const msm::Xyzz<C>* res, typename C::Fe* pre, int cnt, size_t base, size_t stride, u32* out, int out_fmt,
+                                      uint8_t* out_inf) {
+  using Fe = typename C::Fe;
+  constexpr int NW = C::NW;
+  Fe acc; C::fe_one(acc);
+#pragma unroll 1
+  for (int j = 0; j < cnt; j++) {
+    pre[j] = acc;
+    if (C::fe_is_zero(res[j].zz)) continue;
+    Fe w;
+    C::fe_mul(w, res[j].zz, res[j].zzz);
+    C::fe_mul(acc, acc, w);
+  }
+  Fe ai;
+  C::fe_inv(ai, acc);
+#pragma unroll 1
+  for (int j = cnt - 1; j >= 0; j--) {
+    const size_t i = base + (size_t)j * stride;
+    Fe one, zero, wi, t, x, y;
+    C::fe_one(one); C::fe_zero(zero);
+    const bool zr = C::fe_is_zero(res[j].zz);
+    if (zr) { x = zero; y = zero; }
+    else {
+      C::fe_mul(wi, ai, pre[j]);                  // 1 / (ZZ ZZZ)
+      C::fe_mul(t, res[j].zz, res[j].zzz);
+      C::fe_mul(ai, ai, t);
+      C::fe_mul(t, wi, res[j].zzz);               // 1 / ZZ
+      C::fe_mul(x, res[j].x, t);
+      C::fe_mul(t, wi, res[j].zz);                // 1 / ZZZ
+      C::fe_mul(y, res[j].y, t);
+    }
+    if (out_fmt == FMT_PROJECTIVE) {
+      if (zr) y = one;
+      u32* o = out + i * 3 * NW;
+      C::fe_store(o, x); C::fe_store(o + NW, y); C::fe_store(o + 2 * NW, zr ? zero : one);
+    } else {
+      u32* o = out + i * 2 * NW;
+      C::fe_store(o, x); C::fe_store(o + NW, y);
+      if (out_inf) out_inf[i] = zr ? 1 : 0;
+    }
+  }
+}
+
 template <class C, int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) mul_kernel(const u32* scalars, const AffEntry<C>* table, u32* out, int out_fmt,
                                                          uint8_t* out_inf, size_t n) {
   constexpr int NW = C::NW;
-  Jac<C> res[BATCH];
+  msm::Xyzz<C> res[BATCH];
   typename C::Fe pre[BATCH];
   const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,8 +138,8 @@ __global__ void __launch_bounds__(256, WAVES) mul_kernel(const u32* scalars, con
       const bool flip = !mp_geq<NW>(t, k);          // n - k < k
 #pragma unroll
       for (int w = 0; w < NW; w++) k[w] = flip ? t[w] : k[w];
-      Jac<C> acc;
-      jac::set_infinity<C>(acc);
+      msm::Xyzz<C> acc;                           // XYZZ: 8M + 2S per addition, no doubling in this loop
+      msm::xyzz_set_infinity<C>(acc);
       u32 carry = 0;
 #pragma unroll 1
       for (int j = 0; j < nwin<C>(); j++) {
@@ -104,13 +153,13 @@ __global__ void __launch_bounds__(256, WAVES) mul_kernel(const u32* scalars, con
           const AffEntry<C>* e = table + (size_t)j * ENTRIES + ((sd < 0 ? -sd : sd) - 1);
           typename C::Fe x = e->x, y = e->y;
           if ((sd < 0) != flip) C::fe_neg(y, y);
-          jac::add_mixed<C>(acc, x, y);
+          msm::xyzz_add_mixed<C>(acc, x, y);
         }
       }
       res[b] = acc;
       cnt = b + 1;
     }
-    jac::store_batch_affine<C>(res, pre, cnt, base, T, out, out_fmt, out_inf);
+    store_batch_affine_xyzz<C>(res, pre, cnt, base, T, out, out_fmt, out_inf);
   }
 }
 
@@ -176,11 +225,13 @@ __global__ void __launch_bounds__(256) table_scalars_kernel(u32* out, size_t fir
   }
 }
 
+// The accumulator is in XYZZ coordinates (round 3; Jacobian before): an addition of an affine table entry costs 8M + 2S
+// instead of 8M + 3S, and this loop has no doubling to make the fourth coordinate expensive.
 template <class C, int WB, int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars, const AffEntry<C>* table, u32* out, int out_fmt,
                                                            uint8_t* out_inf, size_t n) {
   constexpr int NW = C::NW;
-  Jac<C> res[BATCH];
+  msm::Xyzz<C> res[BATCH];
   typename C::Fe pre[BATCH];
   const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,9 +249,9 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
       const bool flip = !mp_geq<NW>(t, k);
 #pragma unroll
       for (int w = 0; w < NW; w++) k[w] = flip ? t[w] : k[w];
-      Jac<C> acc;
-      jac::set_infinity<C>(acc);
-      int filled = 0;                                     // 0: empty, 1: one entry (affine, Z = 1), 2: a Jacobian sum
+      msm::Xyzz<C> acc;
+      msm::xyzz_set_infinity<C>(acc);
+      int filled = 0;                                     // 0: empty, 1: one entry (affine, ZZ = ZZZ = 1), 2: a sum
       u32 carry = 0;
 #pragma unroll 1
       for (int j = 0; j < nwin_wide<C, WB>(); j++) {
@@ -217,16 +268,16 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
           const AffEntry<C>* e = table + (size_t)j * wide_entries<WB>() + ((sd < 0 ? -sd : sd) - 1);
           typename C::Fe x = e->x, y = e->y;
           if ((sd < 0) != flip) C::fe_neg(y, y);
-          // the second entry meets an accumulator with Z = 1: 4M + 2S instead of 8M + 3S (one of the nine additions of a 26-bit-window
-          // multiplication; the lanes of a wave disagree about `filled` only after a zero digit, 2^-WB per window)
-          if (filled == 1) { jac::add_affine<C>(acc, x, y); filled = 2; }
-          else { jac::add_mixed<C>(acc, x, y); filled = filled ? 2 : 1; }
+          // the second entry meets an accumulator with ZZ = ZZZ = 1: 4M + 2S instead of 8M + 2S (one of the nine additions of a
+          // 26-bit-window multiplication; the lanes of a wave disagree about `filled` only after a zero digit, 2^-WB per window)
+          if (filled == 1) { msm::xyzz_add_affine<C>(acc, x, y); filled = 2; }
+          else { msm::xyzz_add_mixed<C>(acc, x, y); filled = filled ? 2 : 1; }
         }
       }
       res[b] = acc;
       cnt = b + 1;
     }
-    jac::store_batch_affine<C>(res, pre, cnt, base, T, out, out_fmt, out_inf);
+    store_batch_affine_xyzz<C>(res, pre, cnt, base, T, out, out_fmt, out_inf);
   }
 }
 

@@ -85,6 +85,35 @@ ECGPU_HD void xyzz_add_mixed(Xyzz<C>& p, const typename C::Fe& x2, const typenam
   C::fe_sub(q, q, p.x); C::fe_mul(q, r, q);                  // R (Q - X3)
   C::fe_sub(p.y, q, t);
 }
+// p += (x2, y2) for p = (X1, Y1, 1, 1) AFFINE and finite (the caller knows: the first addition after a set): 4M + 2S, ZZ3 = PP and
+// ZZZ3 = PPP fall out of the formula.  Same special cases by control flow.
+template <class C>
+ECGPU_HD void xyzz_add_affine(Xyzz<C>& p, const typename C::Fe& x2, const typename C::Fe& y2) {
+  using Fe = typename C::Fe;
+  Fe pp, r, t, q;
+  C::fe_sub(pp, x2, p.x);
+  C::fe_sub(r, y2, p.y);
+  if (__builtin_expect(C::fe_is_zero_fast(pp), 0)) {
+    if (C::fe_is_zero(r)) {
+      Jac<C> d;
+      d.x = x2; d.y = y2; C::fe_one(d.z);
+      pt_dbl<C>(d);
+      p.x = d.x; p.y = d.y;
+      C::fe_sqr(p.zz, d.z); C::fe_mul(p.zzz, p.zz, d.z);
+    } else {
+      xyzz_set_infinity<C>(p);
+    }
+    return;
+  }
+  C::fe_sqr(p.zz, pp);                                       // ZZ3 = PP
+  C::fe_mul(q, p.x, p.zz);                                   // Q = X1 PP
+  C::fe_mul(p.zzz, p.zz, pp);                                // ZZZ3 = PPP
+  C::fe_sqr(t, r);
+  C::fe_sub(t, t, p.zzz); C::fe_sub(t, t, q); C::fe_sub(p.x, t, q);    // X3 = R^2 - PPP - 2Q
+  C::fe_mul(t, p.y, p.zzz);                                  // Y1 PPP
+  C::fe_sub(q, q, p.x); C::fe_mul(q, r, q);                  // R (Q - X3)
+  C::fe_sub(p.y, q, t);
+}
 // p += q, both in XYZZ coordinates (add-2008-s: 12M + 2S; a bucket left in pieces by the equal-run bucket sums is the sum of
 // its pieces).  Exceptional cases by control flow: either operand at infinity, the same point (doubling, through the
 // Jacobian doubling), opposite points (infinity).

@@ -105,37 +105,80 @@ ECGPU_HD void jac_add_mixed(JacK256& r, const JacK256& p, const FeK256& x2, cons
   jac_add_mixed(r, x2, y2, zr);
 }
 
+// Doubling of an affine point with update (co-Z, a = 0; 2M + 4S): d = 2P in Jacobian coordinates with Z = 2y, and
+// (qx, qy) = P rewritten to that same denominator, (4 x y^2, 8 y^4).
+ECGPU_HD void coz_double_affine(JacK256& d, FeK256& qx, FeK256& qy, const FeK256& x, const FeK256& y) {
+  FeK256 b, e, m, t;
+  sqr(b, x);                                 // B = x^2
+  sqr(e, y);                                 // E = y^2
+  mul(qx, x, e); shl<2>(qx, qx);             // S = 4 x y^2  (= x Z^2)
+  sqr(qy, e); shl<3>(qy, qy);                // 8 L = 8 y^4  (= y Z^3)
+  shl<1>(m, b); add(m, m, b);                // M = 3 B
+  sqr(t, m);
+  sub(t, t, qx); sub(d.x, t, qx);            // X = M^2 - 2S
+  sub(t, qx, d.x); mul(t, m, t);
+  sub(d.y, t, qy);                           // Y = M (S - X) - 8L
+  shl<1>(d.z, y);                            // Z = 2 y
+}
+
+// Co-Z addition with update (Meloni; 4M + 2S without the new Z): (qx, qy) and (r.x, r.y) are two points with the SAME
+// denominator Z.  r <- q + r with denominator Z h, (qx, qy) <- q rewritten to that denominator, h = qx - r.x (before).
+// Exceptional iff q = +-r, which the table chain (q = P, r = jP, 2 <= j <= 7, P of prime order) never meets.
+ECGPU_HD void coz_add_update(FeK256& rx, FeK256& ry, FeK256& qx, FeK256& qy, FeK256& h) {
+  FeK256 c, w2, d, t;
+  sub(h, qx, rx);
+  sqr(c, h);                                 // C = (X1 - X2)^2
+  mul(qx, qx, c);                            // W1
+  mul(w2, rx, c);                            // W2
+  sub(d, qy, ry);                            // Y1 - Y2
+  sub(t, qx, w2); mul(qy, qy, t);            // A1 = Y1 (W1 - W2)
+  sqr(t, d);
+  sub(t, t, qx); sub(rx, t, w2);             // X3 = D - W1 - W2
+  sub(t, qx, rx); mul(t, d, t);
+  sub(ry, t, qy);                            // Y3 = (Y1 - Y2)(W1 - X3) - A1
+}
+
 // [P, 2P, .., 8P] with a common denominator.  On return tab[j-1] = (x', beta x', y') are the affine
 // coordinates of jP (slots 2(j-1) and, with beta*x, 2(j-1)+1) on the curve isomorphic by u = `zglobal`
 // (x' = x u^2, y' = y u^3), i.e. Jacobian
 // coordinates (x', y', zglobal) of jP on secp256k1.  P must not be the identity.
+// The chain 2P, 3P = 2P + P, .. runs in co-Z form (round 3: 6 + 6 x 6 multiplications instead of 7 + 6 x 11): every step
+// rewrites P to the denominator of the new multiple, so the additions are co-Z additions, no Z is ever multiplied out (only
+// the ratios h_j = Z_(j+1) / Z_j are kept) and the last rewritten P IS entry 0 at the common denominator.
 ECGPU_HD void table_build_globalz(TabSlotK256* tab, FeK256& zglobal, const FeK256& px, const FeK256& py) {
-  JacK256 m[8];       // m[j] = (j+1) P, Jacobian
-  FeK256 zr[8];       // zr[j] = Z(m[j]) / Z(m[j-1]),  j >= 2
-  m[0].x = px; m[0].y = py; set_one(m[0].z);
-  jac_double_affine(m[1], px, py);
+  FeK256 mx[8], my[8];   // (mx[j], my[j]) = (j+1) P over the denominator Z_j;  Z_1 = 2 y, Z_j = Z_(j-1) zr[j]
+  FeK256 zr[8];
+  JacK256 d;
+  FeK256 qx, qy;
+  coz_double_affine(d, qx, qy, px, py);
+  mx[1] = d.x; my[1] = d.y;
+  FeK256 rx = d.x, ry = d.y;
 #pragma unroll 1
-  for (int j = 2; j < 8; j++) jac_add_mixed(m[j], m[j - 1], px, py, &zr[j]);
-  zglobal = m[7].z;
+  for (int j = 2; j < 8; j++) {
+    coz_add_update(rx, ry, qx, qy, zr[j]);
+    mx[j] = rx; my[j] = ry;
+  }
   FeK256 beta_; beta(beta_);
-  // scale m[j] to the denominator of m[7]: s_j = Z7 / Z_j = prod_{i > j} zr[i]
+  // scale (j+1)P to the denominator of 8P: s_j = Z7 / Z_j = prod_{i > j} zr[i]
   FeK256 s; set_one(s);
   constexpr int SS = K256_SLOT_STRIDE;
-  tab[7 * SS].x = m[7].x; tab[7 * SS].y = m[7].y;
-  if constexpr (SS == 2) { tab[15].y = m[7].y; mul(tab[15].x, m[7].x, beta_); }
+  tab[7 * SS].x = mx[7]; tab[7 * SS].y = my[7];
+  if constexpr (SS == 2) { tab[15].y = my[7]; mul(tab[15].x, mx[7], beta_); }
 #pragma unroll 1
-  for (int j = 6; j >= 0; j--) {
-    if (j >= 1) mul(s, s, zr[j + 1]);        // s = Z7 / Z_j for j >= 1 (Z_1 = Z(m[1]))
-    else mul(s, s, m[1].z);                  // j = 0: Z_0 = 1, so s = Z7
+  for (int j = 6; j >= 1; j--) {
+    mul(s, s, zr[j + 1]);                    // s = Z7 / Z_j
     FeK256 s2, s3;
     sqr(s2, s);
     mul(s3, s2, s);
     FeK256 tx, ty;
-    mul(tx, m[j].x, s2);
-    mul(ty, m[j].y, s3);
+    mul(tx, mx[j], s2);
+    mul(ty, my[j], s3);
     tab[SS * j].x = tx; tab[SS * j].y = ty;
     if constexpr (SS == 2) { tab[2 * j + 1].y = ty; mul(tab[2 * j + 1].x, tx, beta_); }
   }
+  mul(zglobal, s, d.z);                      // Z7 = (Z7 / Z_1) 2y
+  tab[0].x = qx; tab[0].y = qy;              // P over Z7: the last rewrite of the chain
+  if constexpr (SS == 2) { tab[1].y = qy; mul(tab[1].x, qx, beta_); }
 }
 
 // Adds digit d of one GLV half: d in [-8, 8], `lam` selects beta*x, `neg` is the sign of that half.

@@ -15,7 +15,7 @@
 //     signs, and two mixed additions (8M + 3S) executed for EVERY digit; a zero digit or an empty accumulator is resolved by
 //     masks afterwards (the accumulator's "empty" state is itself a mask that the digits update, not a test of Z);
 //   * per-lane batched conversion of the results to affine (one inversion per pass).
-// 128 x 7 + 66 x 11 + 33 + ~115 = ~1 770 field multiplications (and a third of the complete formulas' field additions)
+// 128 x 7 + 66 x 11 + 33 + ~80 = ~1 735 field multiplications (and a third of the complete formulas' field additions)
 // instead of the reference schedule's 1 984 + 272.  Digits by the reference's branch-free recoding (Radix16Decomposition).
 //
 // Why the Jacobian mixed addition never meets an exceptional case.  Let L = {(x, y) : x + y lambda = 0 mod n}, the lattice
@@ -152,27 +152,29 @@ ECGPU_HD void lane_pass_k256(const u32* scalars, const u32* points, int pt_fmt, 
       k256_mask_select(pz, inf_mask, one, pz);
     }
     // ---- the unit's table [P .. 8P] with the common denominator Z8 (mulfast_k256.hpp::table_build_globalz, branch-free and
-    //      through the workspace): m_j = jP Jacobian, zr_j = Z(m_j) / Z(m_(j-1)); entry j-1 <- (X_j s^2, Y_j s^3), s = Z8 / Z_j
+    //      through the workspace): the co-Z chain 2P, 3P = 2P + P, .. rewrites P to the denominator of every new multiple, so
+    //      each step is a co-Z addition (4M + 2S, no Z multiplied out; exception-free: (j -+ 1) P = O is impossible), the ratios
+    //      zr_j = Z_j / Z_(j-1) are kept, entry j-1 <- (X_j s^2, Y_j s^3) with s = Z8 / Z_j, and the last rewrite of P is entry 0
     FeK256 zfix;
     {
       JacK256 m;
-      k256::jac_double_affine(m, px, py);                       // 2P (P is finite and has no 2-torsion)
-      fe_st<C>(ws, K256_CT_TAB, px); fe_st<C>(ws, K256_CT_TAB + CW, py);
+      FeK256 qx, qy;
+      k256::coz_double_affine(m, qx, qy, px, py);               // 2P (P is finite and has no 2-torsion), P over Z = 2y
       fe_st<C>(ws, K256_CT_TAB + 4, m.x); fe_st<C>(ws, K256_CT_TAB + 4 + CW, m.y);
       const FeK256 z2 = m.z;
 #pragma unroll 1
       for (int j = 2; j < 8; j++) {
         FeK256 h;
-        k256_add_mixed_raw(m, px, py, &h);                       // (j + 1) P = jP + P
+        k256::coz_add_update(m.x, m.y, qx, qy, h);               // (j + 1) P = jP + P
         fe_st<C>(ws, K256_CT_TAB + 4 * j, m.x); fe_st<C>(ws, K256_CT_TAB + 4 * j + CW, m.y);
         fe_st<C>(ws, K256_CT_ZR + CW * j, h);
       }
-      k256::mul(zfix, m.z, pz);                                  // back from both isomorphisms at the end
+      fe_st<C>(ws, K256_CT_TAB, qx); fe_st<C>(ws, K256_CT_TAB + CW, qy);
       FeK256 s = one;
 #pragma unroll 1
-      for (int j = 6; j >= 0; j--) {
+      for (int j = 6; j >= 1; j--) {
         FeK256 f;
-        if (j >= 1) fe_ld<C>(f, ws, K256_CT_ZR + CW * (j + 1)); else f = z2;     // public: the loop counter
+        fe_ld<C>(f, ws, K256_CT_ZR + CW * (j + 1));
         k256::mul(s, s, f);
         FeK256 s2, s3, tx, ty;
         k256::sqr(s2, s);
@@ -182,6 +184,8 @@ ECGPU_HD void lane_pass_k256(const u32* scalars, const u32* points, int pt_fmt, 
         k256::mul(ty, ty, s3);
         fe_st<C>(ws, K256_CT_TAB + 4 * j, tx); fe_st<C>(ws, K256_CT_TAB + 4 * j + CW, ty);
       }
+      k256::mul(s, s, z2);                                       // Z8
+      k256::mul(zfix, s, pz);                                    // back from both isomorphisms at the end
     }
     // ---- the scalar: GLV split and digits (mul.rs:260-305), all branch-free
     u32 k[NW];
