@@ -62,25 +62,28 @@ WORK = {
     # reference schedule: 128 doublings (6M+2S) + 80 complete additions (12M) + to_affine (255S + 17M)
     "k256_varbase_ref": (128 * 6 + 80 * 12 + 17, 128 * 2 + 255),
     # throughput schedule (csrc/mulfast_k256.hpp), batch of 32 results per inversion
-    #   table   : 1 dbl (3M+4S) + 6 mixed adds (8M+3S) + rescale 7M + 7x(3M+1S) + 8 beta*x            =  87M + 29S
+    #   table   : co-Z chain (round 3): doubling with update 2M+4S + 6 co-Z additions (4M+2S, no Z) + rescale of 6 entries
+    #             6M + 6x(3M+1S) + common Z 1M + 8 beta*x (until then 1 dbl + 6 mixed adds + rescale of 7: 87M + 29S)  =  59M + 22S
     #   loop    : 128 dbl (3M+4S) + 66 * 15/16 mixed adds (8M+3S)                                      = 879M + 697.6S
     #   output  : 2M (global Z) + batched normalise 6M+1S + (255S+15M)/32                              =   9M +   9S
-    "k256_varbase_fast": (87 + 128 * 3 + 66 * 15 / 16 * 8 + 9, 29 + 128 * 4 + 66 * 15 / 16 * 3 + 9),
-    # 10 signed 26-bit windows (21.5 GB table): 9 mixed additions (the first is a copy) + normalise 6M+1S + (255S+12M)/64
-    "p256_fixedbase": (9 * 8 + 6 + 12 / 64, 9 * 3 + 1 + 255 / 64),
-    # 96 windows x 4 doublings (4M+4S) + 89 mixed additions (97 digits x 15/16, first one a copy) + table (4 dbl,
-    # 3 general additions 11M+5S) + table to affine 8 x (6M+1S) + (385S+14M)/16 + output normalise 6M+1S + (385S+14M)/16
-    # (16 units per lane and pass share the two inversions since round 3; 8 before)
-    "p384_varbase": (1536 + 89 * 8 + 49 + 48 + 14 / 16 + 6 + 14 / 16, 1536 + 89 * 3 + 31 + 8 + 385 / 16 + 1 + 385 / 16),
+    "k256_varbase_fast": (59 + 128 * 3 + 66 * 15 / 16 * 8 + 9, 22 + 128 * 4 + 66 * 15 / 16 * 3 + 9),
+    # 10 signed 26-bit windows (21.5 GB table), XYZZ accumulator (round 3): the first entry is a copy, the second meets ZZ = ZZZ = 1
+    # (4M+2S), 8 mixed additions 8M+2S, normalise 8M + (255S+12M)/64.  (Until then counted as 9 Jacobian additions 8M+3S and 6M+1S.)
+    "p256_fixedbase": (4 + 8 * 8 + 8 + 12 / 64, 2 + 8 * 2 + 255 / 64),
+    # 96 windows x 4 doublings (4M+4S) + 89 mixed additions (97 digits x 15/16, first one a copy) + table as a co-Z chain (round 3:
+    # doubling with update 2M+4S, 6 co-Z additions 4M+2S, 6M for the last denominator = 32M+16S; until then 4 dbl + 3 general additions
+    # 11M+5S = 49M+31S) + table to affine through ONE inverted denominator and the chain's ratios (37M+7S; until then 8 x (6M+1S))
+    # + (385S+14M)/16 + output normalise 6M+1S + (385S+14M)/16 (16 units per lane and pass share the two inversions)
+    "p384_varbase": (1536 + 89 * 8 + 32 + 37 + 14 / 16 + 6 + 14 / 16, 1536 + 89 * 3 + 16 + 7 + 385 / 16 + 1 + 385 / 16),
     # bucket method with GLV halves, 7 windows of 18 / 19 bits at this size: 14 XYZZ mixed additions (8M+2S) per term;
     # per-term share of the endomorphism (1M), of the bucket pieces and of the bucket reduction (1.8 M buckets: XYZZ -> Jacobian
     # and two general additions 12M+4S each; 1.5 M pieces folded) ~ 9M + 3S
     "k256_msm": (14 * 8 + 1 + 9, 14 * 2 + 3),
     # verification = u2 Q (headline kernel) + u1 G (20-bit table at this batch size) + prep / check (57 scalar-field equivalents + 7)
-    "k256_ecdsa_verify": (87 + 128 * 3 + 66 * 15 / 16 * 8 + 9 + 12 * 8 + 6 + 64, 29 + 128 * 4 + 66 * 15 / 16 * 3 + 9 + 12 * 3 + 5),
+    "k256_ecdsa_verify": (59 + 128 * 3 + 66 * 15 / 16 * 8 + 9 + 4 + 11 * 8 + 8 + 64, 22 + 128 * 4 + 66 * 15 / 16 * 3 + 9 + 2 + 11 * 2 + 4),
     # p256 verification = u2 Q (vb::mul_kernel<CurveP256,16,4>: 256 doublings 4M+4S, 60 general additions 11M+5S, table 4 dbl + 3 add,
-    # output normalise 6M+1S + (255S+12M)/8 = 1 740 M + 1 388 S; counted with 8 units per inversion, 16 since round 3: -1 %) + u1 G (20-bit table: 102 M + 41 S) + prep / check (~64 M)
-    "p256_ecdsa_verify": (1740 + 102 + 64, 1388 + 41),
+    # output normalise 6M+1S + (255S+12M)/8 = 1 740 M + 1 388 S; counted with 8 units per inversion, 16 since round 3: -1 %) + u1 G (20-bit table, XYZZ: 100 M + 28 S) + prep / check (~64 M)
+    "p256_ecdsa_verify": (1740 - 28 + 100 + 64, 1388 - 16 + 28),     # - 28 M, - 16 S: the co-Z table chain of round 3
 }
 
 WORKLOADS = {

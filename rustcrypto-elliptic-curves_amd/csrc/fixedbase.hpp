@@ -116,11 +116,36 @@ ECGPU_HD void store_batch_affine_xyzz(const msm::Xyzz<C>* res, typename C::Fe* p
   }
 }
 
+// The accumulator of the digit-indexed fixed-base kernels: XYZZ (8M + 2S per addition of an affine entry, this loop has no doubling to
+// make the fourth coordinate expensive) where the four coordinates fit the register budget - the 256-bit curves: signing with
+// public nonces +3 %, config 3 +1.3 % -, Jacobian (8M + 3S) for P-384, where 48 accumulator registers instead of 36 spill
+// (measured: 5.66 against 5.27 ms per 2^20 with XYZZ; tools/ab_round3d.sh).
+template <class C, bool XYZZ = (C::NW <= 8)>
+struct FbAcc {
+  using Pt = msm::Xyzz<C>;
+  static ECGPU_HD void set_infinity(Pt& p) { msm::xyzz_set_infinity<C>(p); }
+  static ECGPU_HD void add_mixed(Pt& p, const typename C::Fe& x, const typename C::Fe& y) { msm::xyzz_add_mixed<C>(p, x, y); }
+  static ECGPU_HD void add_affine(Pt& p, const typename C::Fe& x, const typename C::Fe& y) { msm::xyzz_add_affine<C>(p, x, y); }
+  static ECGPU_HD void store(const Pt* res, typename C::Fe* pre, int cnt, size_t base, size_t stride, u32* out, int out_fmt, uint8_t* out_inf) {
+    store_batch_affine_xyzz<C>(res, pre, cnt, base, stride, out, out_fmt, out_inf);
+  }
+};
+template <class C>
+struct FbAcc<C, false> {
+  using Pt = Jac<C>;
+  static ECGPU_HD void set_infinity(Pt& p) { jac::set_infinity<C>(p); }
+  static ECGPU_HD void add_mixed(Pt& p, const typename C::Fe& x, const typename C::Fe& y) { jac::add_mixed<C>(p, x, y); }
+  static ECGPU_HD void add_affine(Pt& p, const typename C::Fe& x, const typename C::Fe& y) { jac::add_affine<C>(p, x, y); }
+  static ECGPU_HD void store(const Pt* res, typename C::Fe* pre, int cnt, size_t base, size_t stride, u32* out, int out_fmt, uint8_t* out_inf) {
+    jac::store_batch_affine<C>(res, pre, cnt, base, stride, out, out_fmt, out_inf);
+  }
+};
+
 template <class C, int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) mul_kernel(const u32* scalars, const AffEntry<C>* table, u32* out, int out_fmt,
                                                          uint8_t* out_inf, size_t n) {
   constexpr int NW = C::NW;
-  msm::Xyzz<C> res[BATCH];
+  typename FbAcc<C>::Pt res[BATCH];
   typename C::Fe pre[BATCH];
   const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -138,8 +163,8 @@ __global__ void __launch_bounds__(256, WAVES) mul_kernel(const u32* scalars, con
       const bool flip = !mp_geq<NW>(t, k);          // n - k < k
 #pragma unroll
       for (int w = 0; w < NW; w++) k[w] = flip ? t[w] : k[w];
-      msm::Xyzz<C> acc;                           // XYZZ: 8M + 2S per addition, no doubling in this loop
-      msm::xyzz_set_infinity<C>(acc);
+      typename FbAcc<C>::Pt acc;
+      FbAcc<C>::set_infinity(acc);
       u32 carry = 0;
 #pragma unroll 1
       for (int j = 0; j < nwin<C>(); j++) {
@@ -153,13 +178,13 @@ __global__ void __launch_bounds__(256, WAVES) mul_kernel(const u32* scalars, con
           const AffEntry<C>* e = table + (size_t)j * ENTRIES + ((sd < 0 ? -sd : sd) - 1);
           typename C::Fe x = e->x, y = e->y;
           if ((sd < 0) != flip) C::fe_neg(y, y);
-          msm::xyzz_add_mixed<C>(acc, x, y);
+          FbAcc<C>::add_mixed(acc, x, y);
         }
       }
       res[b] = acc;
       cnt = b + 1;
     }
-    store_batch_affine_xyzz<C>(res, pre, cnt, base, T, out, out_fmt, out_inf);
+    FbAcc<C>::store(res, pre, cnt, base, T, out, out_fmt, out_inf);
   }
 }
 
@@ -225,13 +250,12 @@ __global__ void __launch_bounds__(256) table_scalars_kernel(u32* out, size_t fir
   }
 }
 
-// The accumulator is in XYZZ coordinates (round 3; Jacobian before): an addition of an affine table entry costs 8M + 2S
-// instead of 8M + 3S, and this loop has no doubling to make the fourth coordinate expensive.
+// The accumulator is FbAcc<C>: XYZZ on the 256-bit curves (round 3; Jacobian before), Jacobian on P-384.
 template <class C, int WB, int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars, const AffEntry<C>* table, u32* out, int out_fmt,
                                                            uint8_t* out_inf, size_t n) {
   constexpr int NW = C::NW;
-  msm::Xyzz<C> res[BATCH];
+  typename FbAcc<C>::Pt res[BATCH];
   typename C::Fe pre[BATCH];
   const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,9 +273,9 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
       const bool flip = !mp_geq<NW>(t, k);
 #pragma unroll
       for (int w = 0; w < NW; w++) k[w] = flip ? t[w] : k[w];
-      msm::Xyzz<C> acc;
-      msm::xyzz_set_infinity<C>(acc);
-      int filled = 0;                                     // 0: empty, 1: one entry (affine, ZZ = ZZZ = 1), 2: a sum
+      typename FbAcc<C>::Pt acc;
+      FbAcc<C>::set_infinity(acc);
+      int filled = 0;                                     // 0: empty, 1: one entry (affine: Z = 1 / ZZ = ZZZ = 1), 2: a sum
       u32 carry = 0;
 #pragma unroll 1
       for (int j = 0; j < nwin_wide<C, WB>(); j++) {
@@ -270,14 +294,14 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
           if ((sd < 0) != flip) C::fe_neg(y, y);
           // the second entry meets an accumulator with ZZ = ZZZ = 1: 4M + 2S instead of 8M + 2S (one of the nine additions of a
           // 26-bit-window multiplication; the lanes of a wave disagree about `filled` only after a zero digit, 2^-WB per window)
-          if (filled == 1) { msm::xyzz_add_affine<C>(acc, x, y); filled = 2; }
-          else { msm::xyzz_add_mixed<C>(acc, x, y); filled = filled ? 2 : 1; }
+          if (filled == 1) { FbAcc<C>::add_affine(acc, x, y); filled = 2; }
+          else { FbAcc<C>::add_mixed(acc, x, y); filled = filled ? 2 : 1; }
         }
       }
       res[b] = acc;
       cnt = b + 1;
     }
-    store_batch_affine_xyzz<C>(res, pre, cnt, base, T, out, out_fmt, out_inf);
+    FbAcc<C>::store(res, pre, cnt, base, T, out, out_fmt, out_inf);
   }
 }
 

@@ -137,6 +137,52 @@ ECGPU_HD void add_affine(Jac<C>& p, const typename C::Fe& x2, const typename C::
   C::fe_sub(p.y, t, h);
 }
 
+// Co-Z arithmetic for table chains P, 2P, 3P = 2P + P, .. (Meloni's additions with update): two points that share their
+// denominator Z add in 4M + 2S without touching Z, and the addend comes back rewritten to the sum's denominator Z h, so
+// the chain never multiplies a Z out - only the ratios h are kept.
+//
+// Doubling with update, a = -3 (4M + 4S; 2M + 4S for an affine input, `z_is_one`): (dx, dy) = 2P over the denominator
+// z2 = 2 Y Z, (qx, qy) = P rewritten to that denominator: (4 X Y^2, 8 Y^4).  P is finite and not of order 2.
+template <class C>
+ECGPU_HD void coz_double_update(typename C::Fe& dx, typename C::Fe& dy, typename C::Fe& z2, typename C::Fe& qx, typename C::Fe& qy, const Jac<C>& p,
+                                bool z_is_one) {
+  static_assert(!C::A_IS_ZERO, "a = -3 (secp256k1 has its own chain in mulfast_k256.hpp)");
+  using Fe = typename C::Fe;
+  Fe t1, t2, al, e;
+  if (z_is_one) C::fe_one(t1); else C::fe_sqr(t1, p.z);
+  C::fe_sub(t2, p.x, t1);
+  C::fe_add(t1, p.x, t1);
+  C::fe_mul(t2, t1, t2);
+  fe_dbl<C>(t1, t2); C::fe_add(al, t1, t2);            // alpha = 3 (X - Z^2)(X + Z^2)
+  fe_dbl<C>(z2, p.y);                                  // 2Y
+  if (!z_is_one) C::fe_mul(z2, z2, p.z);               // Z2 = 2 Y Z
+  C::fe_sqr(e, p.y);                                   // Y^2
+  C::fe_mul(qx, p.x, e); fe_dbl<C>(qx, qx); fe_dbl<C>(qx, qx);      // S = 4 X Y^2
+  C::fe_sqr(qy, e); fe_dbl<C>(qy, qy); fe_dbl<C>(qy, qy); fe_dbl<C>(qy, qy);   // 8 Y^4
+  C::fe_sqr(t1, al);
+  C::fe_sub(t1, t1, qx); C::fe_sub(dx, t1, qx);        // X = alpha^2 - 2S
+  C::fe_sub(t1, qx, dx); C::fe_mul(t1, al, t1);
+  C::fe_sub(dy, t1, qy);                               // Y = alpha (S - X) - 8 Y^4
+}
+// Co-Z addition with update (4M + 2S): (qx, qy) and (rx, ry) share the denominator Z.  r <- q + r over Z h,
+// (qx, qy) <- q over Z h, h = qx - rx (of the inputs).  Exceptional iff q = +-r: the table chains (q = P, r = jP,
+// 2 <= j <= 7, P of prime order) never meet it.
+template <class C>
+ECGPU_HD void coz_add_update(typename C::Fe& rx, typename C::Fe& ry, typename C::Fe& qx, typename C::Fe& qy, typename C::Fe& h) {
+  using Fe = typename C::Fe;
+  Fe c, w2, d, t;
+  C::fe_sub(h, qx, rx);
+  C::fe_sqr(c, h);                                     // C = (X1 - X2)^2
+  C::fe_mul(qx, qx, c);                                // W1
+  C::fe_mul(w2, rx, c);                                // W2
+  C::fe_sub(d, qy, ry);                                // Y1 - Y2
+  C::fe_sub(t, qx, w2); C::fe_mul(qy, qy, t);          // A1 = Y1 (W1 - W2)
+  C::fe_sqr(t, d);
+  C::fe_sub(t, t, qx); C::fe_sub(rx, t, w2);           // X3 = D - W1 - W2
+  C::fe_sub(t, qx, rx); C::fe_mul(t, d, t);
+  C::fe_sub(ry, t, qy);                                // Y3 = (Y1 - Y2)(W1 - X3) - A1
+}
+
 // general addition r = p + q (11M + 5S), all special cases handled
 template <class C>
 ECGPU_HD void add(Jac<C>& r, const Jac<C>& p, const Jac<C>& q) {

@@ -9,14 +9,16 @@
 // the inputs it meets (argument below), not complete on all of E x E:
 //   * k' = min(k, n - k) and +-P by masks, signed 4-bit digits d_j in [-8, 7] by the branch-free recoding
 //     nibble_j(k' + 0x88..8) - 8 plus the carry digit d_top in {0, 1};
-//   * per-lane table [P .. 8P]: 4 Jacobian doublings and 3 additions, all tables of a pass brought to affine form with
-//     ONE inversion (Montgomery's trick), kept in a lane-interleaved global workspace: all lanes of a wave read the same
-//     entry number, so every load of the scan is one contiguous 1 KB row per wave;
+//   * per-lane table [P .. 8P] as a co-Z chain (one doubling with update, six co-Z additions of 4M + 2S: jacobian.hpp;
+//     4 doublings and 3 general additions until late in round 3), all tables of a pass brought to affine form with ONE
+//     inversion over one denominator per table (the chain's ratios give the other seven), kept in a lane-interleaved
+//     global workspace: all lanes of a wave read the same entry number, so every load of the scan is one contiguous 1 KB
+//     row per wave;
 //   * per window 4 Jacobian doublings (a = -3: 4M + 4S, total on every input including Z = 0) and ONE mixed addition
 //     (8M + 3S) of the entry that a masked scan over ALL eight entries picked (arithmetic AND / OR masks, the sign by a
 //     masked negation), executed for every digit; a zero digit or an empty accumulator is resolved by masks afterwards;
 //   * per-lane batched conversion to affine, identity results by masks.
-// 256 x 8 + 65 x 11 + ~190 field multiplications per P-256 result instead of the reference schedule's 4 361 + 269.
+// 256 x 8 + 65 x 11 + ~150 field multiplications per P-256 result instead of the reference schedule's 4 361 + 269.
 //
 // Why the Jacobian addition never meets an exceptional case (P of prime order n, the only kind these curves have
 // besides the identity; 0 <= k' <= (n - 1) / 2):  let s_j = sum_{i >= j} d_i 16^(i - j), so the accumulator is
@@ -25,7 +27,7 @@
 // (-n, n).  The addition is exceptional iff 16 s_(j+1) = 0 or = +-d_j modulo n, hence as integers; 16 | d_j forces
 // d_j = 0.  So the only special operands are an empty accumulator (s_(j+1) = 0: tracked in a mask, the result is then
 // the table entry itself) and a zero digit (the accumulator is kept); once s_j > 0 it stays >= 8.  The table build adds
-// P to jP, j in {2, 4, 6}: exceptional only if (j -+ 1) P = O, impossible for prime n > 7.  An identity INPUT is
+// P to jP, j = 2 .. 7: exceptional only if (j -+ 1) P = O, impossible for prime n > 8.  An identity INPUT is
 // replaced by G under a mask and the result forced to the identity.  Inputs that are not on the curve give unspecified
 // output, as they would violate the reference's type invariants; the instruction stream does not depend on them either.
 // The caveat of every schedule in this library applies: field additions take a rare carry path as a real branch.
@@ -47,8 +49,9 @@ struct LaneMem {
 };
 
 template <class C> constexpr int cw() { return C::NW / 4; }                      // chunks per field element
-// chunk layout of one lane: BATCH * 8 Jacobian entries (x, y, z), then the BATCH * 8 prefix products of the inversion
-template <class C, int BATCH> constexpr int lane_chunks() { return BATCH * 8 * 4 * cw<C>(); }
+// chunk layout of one lane: BATCH * 8 entries (x, y and a z slot for the chain's ratios / a parked result's Z), then the BATCH
+// prefix products of the shared inversions
+template <class C, int BATCH> constexpr int lane_chunks() { return BATCH * (8 * 3 + 1) * cw<C>(); }
 template <class C> constexpr int entry_chunk(int slot, int e) { return (slot * 8 + e) * 3 * cw<C>(); }
 template <class C, int BATCH> constexpr int pre_chunk(int i) { return BATCH * 8 * 3 * cw<C>() + i * cw<C>(); }
 
@@ -112,26 +115,6 @@ ECGPU_HD void add_mixed_raw(Jac<C>& p, const typename C::Fe& x2, const typename 
   C::fe_mul(h, p.y, h);
   C::fe_sub(p.y, t, h);
 }
-// r = p + q, general Jacobian addition 11M + 5S, no exceptional-case handling (table build: jP + P)
-template <class C>
-ECGPU_HD void add_raw(Jac<C>& r, const Jac<C>& p, const Jac<C>& q) {
-  using Fe = typename C::Fe;
-  Fe z1z1, z2z2, u1, u2, s1, s2, h, rr, t, hh, hhh, v;
-  C::fe_sqr(z1z1, p.z); C::fe_sqr(z2z2, q.z);
-  C::fe_mul(u1, p.x, z2z2); C::fe_mul(u2, q.x, z1z1);
-  C::fe_mul(t, q.z, z2z2); C::fe_mul(s1, p.y, t);
-  C::fe_mul(t, p.z, z1z1); C::fe_mul(s2, q.y, t);
-  C::fe_sub(h, u2, u1);
-  C::fe_sub(rr, s2, s1);
-  C::fe_sqr(hh, h); C::fe_mul(hhh, hh, h); C::fe_mul(v, u1, hh);
-  Jac<C> o;
-  C::fe_sqr(t, rr); C::fe_sub(t, t, hhh); C::fe_sub(t, t, v); C::fe_sub(o.x, t, v);
-  C::fe_sub(t, v, o.x); C::fe_mul(t, rr, t);
-  C::fe_mul(s1, s1, hhh); C::fe_sub(o.y, t, s1);
-  C::fe_mul(t, p.z, q.z); C::fe_mul(o.z, t, h);
-  r = o;
-}
-
 // k' = min(k mod n, n - k mod n) and the mask of the flip, branch-free
 template <class C>
 ECGPU_HD u32 scalar_fold(u32* k, const u32* be) {
@@ -201,52 +184,63 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
       fe_mask_select<C>(p.z, inf_mask, one, p.z);
     }
     infs |= (inf_mask & 1u) << s;
-    Jac<C> p2 = p, t3, u;
-    jac::dbl<C>(p2);                           // 2P
-    jac_st<C>(ws, entry_chunk<C>(s, 0), p); jac_st<C>(ws, entry_chunk<C>(s, 1), p2);
-    add_raw<C>(t3, p2, p);                     // 3P
-    jac_st<C>(ws, entry_chunk<C>(s, 2), t3);
-    u = t3; jac::dbl<C>(u);                    // 6P
-    jac_st<C>(ws, entry_chunk<C>(s, 5), u);
-    add_raw<C>(u, u, p);                       // 7P
-    jac_st<C>(ws, entry_chunk<C>(s, 6), u);
-    jac::dbl<C>(p2);                           // 4P
-    jac_st<C>(ws, entry_chunk<C>(s, 3), p2);
-    add_raw<C>(t3, p2, p);                     // 5P
-    jac_st<C>(ws, entry_chunk<C>(s, 4), t3);
-    jac::dbl<C>(p2);                           // 8P
-    jac_st<C>(ws, entry_chunk<C>(s, 7), p2);
+    // co-Z chain (jacobian.hpp): 2P with P rewritten to its denominator, then (e + 1) P = e P + P, every step rewriting P again.
+    // Entry e holds (x, y) of (e + 1) P over the denominator D_e; its z slot the ratio D_e / D_(e-1) (entries 2 .. 7);
+    // entry 0 ends as P over D_7 with D_7 itself in its z slot.  Exception-free: (e -+ 1) P = O is impossible for a point of order n.
+    {
+      Fe rx, ry, qx, qy, zacc, h;
+      jac::coz_double_update<C>(rx, ry, zacc, qx, qy, p, pt_fmt != FMT_PROJECTIVE);       // public: the wire format
+      fe_st<C>(ws, entry_chunk<C>(s, 1), rx); fe_st<C>(ws, entry_chunk<C>(s, 1) + CW, ry);
+#pragma unroll 1
+      for (int e = 2; e < 8; e++) {
+        jac::coz_add_update<C>(rx, ry, qx, qy, h);
+        fe_st<C>(ws, entry_chunk<C>(s, e), rx); fe_st<C>(ws, entry_chunk<C>(s, e) + CW, ry); fe_st<C>(ws, entry_chunk<C>(s, e) + 2 * CW, h);
+        C::fe_mul(zacc, zacc, h);
+      }
+      fe_st<C>(ws, entry_chunk<C>(s, 0), qx); fe_st<C>(ws, entry_chunk<C>(s, 0) + CW, qy); fe_st<C>(ws, entry_chunk<C>(s, 0) + 2 * CW, zacc);
+    }
   }
-  // ---- phase B: all cnt * 8 entries to affine with one inversion (a zero denominator - input not on the curve - is
-  //      replaced by one under a mask so that it cannot poison its neighbours)
+  // ---- phase B: one inversion for the D_7 of all cnt tables (a zero denominator - input not on the curve - is replaced by
+  //      one under a mask so that it cannot poison its neighbours); 1 / D_e = (1 / D_7) prod_{i > e} h_i
   {
     Fe acc = one;
 #pragma unroll 1
-    for (int e = 0; e < cnt * 8; e++) {
-      fe_st<C>(ws, pre_chunk<C, BATCH>(e), acc);
+    for (int s = 0; s < cnt; s++) {
+      fe_st<C>(ws, pre_chunk<C, BATCH>(s), acc);
       Fe z;
-      fe_ld<C>(z, ws, e * 3 * CW + 2 * CW);
+      fe_ld<C>(z, ws, entry_chunk<C>(s, 0) + 2 * CW);
       fe_mask_select<C>(z, fe_zero_mask<C>(z), one, z);
       C::fe_mul(acc, acc, z);
     }
     Fe ai;
     C::fe_inv(ai, acc);
 #pragma unroll 1
-    for (int e = cnt * 8 - 1; e >= 0; e--) {
-      Fe z, zi, t, pre, x, y;
-      fe_ld<C>(z, ws, e * 3 * CW + 2 * CW);
+    for (int s = cnt - 1; s >= 0; s--) {
+      Fe z, zi7, zi, t, t3, pre, x, y, sfx, hh;
+      fe_ld<C>(z, ws, entry_chunk<C>(s, 0) + 2 * CW);
       fe_mask_select<C>(z, fe_zero_mask<C>(z), one, z);
-      fe_ld<C>(pre, ws, pre_chunk<C, BATCH>(e));
-      C::fe_mul(zi, ai, pre);
+      fe_ld<C>(pre, ws, pre_chunk<C, BATCH>(s));
+      C::fe_mul(zi7, ai, pre);
       C::fe_mul(ai, ai, z);
-      C::fe_sqr(t, zi);
-      fe_ld<C>(x, ws, e * 3 * CW);
-      C::fe_mul(x, x, t);
-      fe_st<C>(ws, e * 3 * CW, x);
-      C::fe_mul(t, t, zi);
-      fe_ld<C>(y, ws, e * 3 * CW + CW);
-      C::fe_mul(y, y, t);
-      fe_st<C>(ws, e * 3 * CW + CW, y);
+      C::fe_sqr(t, zi7);
+      C::fe_mul(t3, t, zi7);
+#pragma unroll 1
+      for (int q = 0; q < 2; q++) {              // entries 7 (8P) and 0 (P rewritten): both over D_7
+        const int ch = entry_chunk<C>(s, q ? 0 : 7);
+        fe_ld<C>(x, ws, ch); C::fe_mul(x, x, t); fe_st<C>(ws, ch, x);
+        fe_ld<C>(y, ws, ch + CW); C::fe_mul(y, y, t3); fe_st<C>(ws, ch + CW, y);
+      }
+      fe_ld<C>(sfx, ws, entry_chunk<C>(s, 7) + 2 * CW);
+#pragma unroll 1
+      for (int e = 6; e >= 1; e--) {
+        if (e != 6) { fe_ld<C>(hh, ws, entry_chunk<C>(s, e + 1) + 2 * CW); C::fe_mul(sfx, sfx, hh); }      // D_7 / D_e (public: the loop counter)
+        const int ch = entry_chunk<C>(s, e);
+        C::fe_mul(zi, zi7, sfx);
+        C::fe_sqr(t, zi);
+        fe_ld<C>(x, ws, ch); C::fe_mul(x, x, t); fe_st<C>(ws, ch, x);
+        C::fe_mul(t, t, zi);
+        fe_ld<C>(y, ws, ch + CW); C::fe_mul(y, y, t); fe_st<C>(ws, ch + CW, y);
+      }
     }
   }
   // ---- phase C: the window loop, one unit after the other; results stay in the lane's table slot (entry 0 is free

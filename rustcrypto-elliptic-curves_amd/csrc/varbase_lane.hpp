@@ -3,8 +3,9 @@
 // unsigned 4-bit window and a 16-entry table (primeorder/src/projective.rs:106-150: 4361 / 6473
 // field multiplications); the group element is what is specified, so here:
 //   * Jacobian coordinates (doubling 4M+4S with a halving for a = -3, general addition 11M+5S);
-//   * signed 4-bit digits (k > n/2 is replaced by n - k and -P): table [P .. 8P] of 8 Jacobian points
-//     per lane in a lane-contiguous global workspace, built with 4 doublings and 3 mixed additions;
+//   * signed 4-bit digits (k > n/2 is replaced by n - k and -P): table [P .. 8P] per lane in a lane-contiguous global
+//     workspace, built as a co-Z chain (one doubling with update, six co-Z additions: jacobian.hpp) and brought to affine
+//     form through ONE inverted denominator per table (the chain's ratios give the other seven);
 //   * per-lane batched conversion to affine (one inversion per BATCH results).
 // (The common-Z "effective affine" table used for k256 needs a = 0: on the isomorphic curve the
 // a = -3 doubling shortcut no longer holds.)
@@ -18,12 +19,13 @@ namespace vb {
 
 template <class C> constexpr int nwin() { return 2 * C::NB + 1; }   // nibbles + the carry digit
 
-// workspace of one lane: BATCH tables of 8 points (first as Jacobian triples, then overwritten by affine x, y) and the
-// BATCH * 8 prefix products of the shared inversion
+// workspace of one lane: BATCH tables of 8 points - entry e is (e + 1) P as (x, y) over the denominator D_e of the co-Z chain,
+// overwritten by the affine x, y; its z slot holds the chain's ratio D_e / D_(e-1) (entries 2 .. 7), D_1 (entry 1) and D_7
+// (entry 0, whose x, y are P rewritten to D_7) - and the BATCH prefix products of the shared inversion
 template <class C, int BATCH>
 struct LaneWs {
   Jac<C> tab[BATCH][8];
-  typename C::Fe pre[BATCH * 8];
+  typename C::Fe pre[BATCH];
 };
 
 // One pass of one lane: units base, base + T, .., base + (BATCH / NT - 1) T (those below n).  A unit is a linear
@@ -32,20 +34,21 @@ struct LaneWs {
 // term t of unit i is scalar / point number i * NT + t, and the NT tables of a unit take NT of the BATCH table slots.
 // Per-lane tables live in a lane-contiguous global workspace (in the private segment a lane-divergent index turns
 // every entry read into scattered dword rows: 3.5x the fetch traffic on the k256 kernel).
-// The BATCH tables of a pass are built first and brought to affine form with ONE inversion (Montgomery's trick over
-// BATCH * 8 denominators, 7 multiplications per entry), so that every addition of the main loop is a mixed one
-// (8M + 3S instead of 11M + 5S).
+// The BATCH tables of a pass are built first and brought to affine form with ONE inversion, so that every addition of the
+// main loop is a mixed one (8M + 3S instead of 11M + 5S).  Until late in round 3 a table was 4 doublings and 3 general
+// additions (80 multiplications) and the inversion ran over all BATCH * 8 denominators (7 multiplications per entry); now
+// the chain is co-Z (8 + 6 x 6 + 6 for the last denominator), Montgomery's trick runs over ONE denominator per table and
+// the other entries' inverses follow from the chain's ratios (5 multiplications per entry): ~95 instead of ~136 per table.
 // Measured against Jacobian tables with general additions: +8.5 % for P-384 (16.6 against 15.3 M/s at 2^21), +3.7 % for
 // P-256 (53.2 against 51.3; in round 1, with a square-and-multiply inversion of 384 multiplications instead of the
 // 267-multiplication chain, the extra pass over the tables cost P-256 more than the cheaper additions saved).
-template <class C, int BATCH, int NT = 1, int AFFINE = -1>
+template <class C, int BATCH, int NT = 1>
 ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf, size_t n, size_t base,
                         size_t T, LaneWs<C, BATCH>& ws, const DigitMem& dm) {
   static_assert(BATCH % NT == 0 && BATCH <= 32, "table slots per pass");
   constexpr int NW = C::NW;
   constexpr int UB = BATCH / NT;               // units per pass
   using Fe = typename C::Fe;
-  constexpr bool AFFINE_TABLES = (AFFINE != 0);      // AFFINE = 0: Jacobian tables and general additions (kept for measurements)
   Jac<C> res[UB];
   Fe pre[UB];
   const int pw = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * NW;
@@ -93,47 +96,54 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
     if (flip) C::fe_neg(p.y, p.y);
     flips |= (flip ? 1u : 0u) << s;
     infs |= (p_inf ? 1u : 0u) << s;
+    // co-Z chain: 2P with P rewritten to its denominator, then (e + 1) P = e P + P, every step rewriting P again
     Jac<C>* tab = ws.tab[s];
-    Jac<C> p2 = p, t3, u;
-    jac::dbl<C>(p2);                       // 2P
-    tab[0] = p; tab[1] = p2;
-    jac::add<C>(t3, p2, p);                // 3P
-    tab[2] = t3;
-    u = t3; jac::dbl<C>(u);                // 6P
-    tab[5] = u;
-    jac::add<C>(u, u, p);                  // 7P
-    tab[6] = u;
-    jac::dbl<C>(p2);                       // 4P
-    tab[3] = p2;
-    jac::add<C>(t3, p2, p);                // 5P
-    tab[4] = t3;
-    jac::dbl<C>(p2);                       // 8P
-    tab[7] = p2;
+    Fe rx, ry, qx, qy, zacc, h;
+    jac::coz_double_update<C>(rx, ry, zacc, qx, qy, p, pt_fmt != FMT_PROJECTIVE);
+    tab[1].x = rx; tab[1].y = ry;
+#pragma unroll 1
+    for (int e = 2; e < 8; e++) {
+      jac::coz_add_update<C>(rx, ry, qx, qy, h);
+      tab[e].x = rx; tab[e].y = ry; tab[e].z = h;
+      C::fe_mul(zacc, zacc, h);                // D_e = D_(e-1) h_e
+    }
+    tab[0].x = qx; tab[0].y = qy; tab[0].z = zacc;       // P over D_7, and D_7 itself
   }
-  // ---- phase B: all cnt * NT * 8 entries to affine with one inversion (a zero denominator - only possible for input
-  //      that is not on the curve - is replaced by one so that it cannot poison its neighbours)
-  if constexpr (AFFINE_TABLES) {
+  // ---- phase B: one inversion for the D_7 of all cnt * NT tables (a zero denominator - only possible for input that is
+  //      not on the curve - is replaced by one so that it cannot poison its neighbours); 1 / D_e = (1 / D_7) prod_{i > e} h_i
+  {
     Fe acc; C::fe_one(acc);
 #pragma unroll 1
-    for (int e = 0; e < cnt * NT * 8; e++) {
-      ws.pre[e] = acc;
-      Fe z = ws.tab[e >> 3][e & 7].z;
+    for (int s = 0; s < cnt * NT; s++) {
+      ws.pre[s] = acc;
+      Fe z = ws.tab[s][0].z;
       if (C::fe_is_zero(z)) C::fe_one(z);
       C::fe_mul(acc, acc, z);
     }
     Fe ai;
     C::fe_inv(ai, acc);
 #pragma unroll 1
-    for (int e = cnt * NT * 8 - 1; e >= 0; e--) {
-      Jac<C>& q = ws.tab[e >> 3][e & 7];
-      Fe z = q.z, zi, t;
+    for (int s = cnt * NT - 1; s >= 0; s--) {
+      Jac<C>* tab = ws.tab[s];
+      Fe z = tab[0].z, zi7, zi, t, sfx;
       if (C::fe_is_zero(z)) C::fe_one(z);
-      C::fe_mul(zi, ai, ws.pre[e]);
+      C::fe_mul(zi7, ai, ws.pre[s]);
       C::fe_mul(ai, ai, z);
-      C::fe_sqr(t, zi);
-      C::fe_mul(q.x, q.x, t);
-      C::fe_mul(t, t, zi);
-      C::fe_mul(q.y, q.y, t);
+      C::fe_sqr(t, zi7);
+      C::fe_mul(tab[7].x, tab[7].x, t);
+      C::fe_mul(tab[0].x, tab[0].x, t);
+      C::fe_mul(t, t, zi7);
+      C::fe_mul(tab[7].y, tab[7].y, t);
+      C::fe_mul(tab[0].y, tab[0].y, t);
+#pragma unroll 1
+      for (int e = 6; e >= 1; e--) {
+        if (e == 6) sfx = tab[7].z; else C::fe_mul(sfx, sfx, tab[e + 1].z);      // D_7 / D_e
+        C::fe_mul(zi, zi7, sfx);
+        C::fe_sqr(t, zi);
+        C::fe_mul(tab[e].x, tab[e].x, t);
+        C::fe_mul(t, t, zi);
+        C::fe_mul(tab[e].y, tab[e].y, t);
+      }
     }
   }
   // ---- phase C: signed 4-bit windows over the tables; the NT terms of a unit share the doublings
@@ -195,17 +205,10 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
           sd = (int)((word >> (4 * (j & 7))) & 15u) - 8;
         }
         if (sd != 0) {
-          const Jac<C>* tab = ws.tab[b * NT + tt];
-          if constexpr (AFFINE_TABLES) {
-            const Jac<C>& e = tab[(sd < 0 ? -sd : sd) - 1];
-            Fe ex = e.x, ey = e.y;
-            if (sd < 0) C::fe_neg(ey, ey);
-            jac::add_mixed<C>(acc, ex, ey);
-          } else {
-            Jac<C> e = tab[(sd < 0 ? -sd : sd) - 1];
-            if (sd < 0) C::fe_neg(e.y, e.y);
-            jac::add<C>(acc, acc, e);
-          }
+          const Jac<C>& e = ws.tab[b * NT + tt][(sd < 0 ? -sd : sd) - 1];
+          Fe ex = e.x, ey = e.y;
+          if (sd < 0) C::fe_neg(ey, ey);
+          jac::add_mixed<C>(acc, ex, ey);
         }
       }
     }
