@@ -32,7 +32,11 @@ struct P256Mod {
   static constexpr int NEG_OFF[1] = {0};
   // a separate squaring (28 instead of 64 products) pays for the extra pass over the columns only when the
   // product dominates the reduction: counted out for 8 words (905 vs 920 cycles), taken for 12 (P384Mod)
+#ifdef ECGPU_P256_DEDICATED_SQR                    // A/B switch (tools/ab_round3e.sh)
+  static constexpr bool DEDICATED_SQR = true;
+#else
   static constexpr bool DEDICATED_SQR = false;
+#endif
 };
 struct P384Mod {
   static constexpr int N = 12;
