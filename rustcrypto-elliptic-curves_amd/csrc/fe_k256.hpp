@@ -106,6 +106,45 @@ ECGPU_HD void mul(FeK256& r, const FeK256& a, const FeK256& b) {
   fold_top_fast(r.v, T);
 }
 
+// r = a * b + e * f mod p (weakly reduced): both products ride on the same column accumulators and share ONE reduction (the
+// point formulas end in differences of two products: Y3 = R (V - X3) - Y1 HHH).  A column holds up to 16 products plus the
+// fold term, < 2^69: the 96-bit accumulator has room.  The sum of the two products can reach 2^513, so word 16 (one bit) exists:
+// 2^512 = C^2 mod p, i.e. it adds C to the overflow count T that fold_top_fast multiplies by C.
+template <int K>
+ECGPU_HD void mul2_high_column(u32* h, Acc96& c, const u32* a, const u32* b, const u32* e, const u32* f) {
+  mac_product_column<8, K, 0, true>(c, a, b, nullptr, nullptr);     // c.hi == 0: fresh accumulator or just popped
+  mac_product_column<8, K, 0, false>(c, e, f, nullptr, nullptr);
+  h[K - 8] = acc_pop(c);
+}
+template <int K>
+ECGPU_HD void mul2_low_column(u32* t, Acc96& c, const u32* a, const u32* b, const u32* e, const u32* f, const u32* h) {
+  const u32 xa[1] = {h[K]}, xb[1] = {C_LO};
+  mac_product_column<8, K, 1, true>(c, a, b, xa, xb);
+  mac_product_column<8, K, 0, false>(c, e, f, nullptr, nullptr);
+  t[K] = acc_pop(c);
+}
+ECGPU_HD void mul_add2(FeK256& r, const FeK256& a, const FeK256& b, const FeK256& e, const FeK256& f) {
+  u32 h[8], t[8];
+  Acc96 c{0, 0};
+  mul2_high_column<8>(h, c, a.v, b.v, e.v, f.v);  mul2_high_column<9>(h, c, a.v, b.v, e.v, f.v);
+  mul2_high_column<10>(h, c, a.v, b.v, e.v, f.v); mul2_high_column<11>(h, c, a.v, b.v, e.v, f.v);
+  mul2_high_column<12>(h, c, a.v, b.v, e.v, f.v); mul2_high_column<13>(h, c, a.v, b.v, e.v, f.v);
+  mul2_high_column<14>(h, c, a.v, b.v, e.v, f.v);
+  h[7] = (u32)c.lo;
+  const u32 h8 = (u32)(c.lo >> 32);                 // word 16 of the sum: 0 or 1
+  c.lo = 0; c.hi = 0;
+  mul2_low_column<0>(t, c, a.v, b.v, e.v, f.v, h); mul2_low_column<1>(t, c, a.v, b.v, e.v, f.v, h);
+  mul2_low_column<2>(t, c, a.v, b.v, e.v, f.v, h); mul2_low_column<3>(t, c, a.v, b.v, e.v, f.v, h);
+  mul2_low_column<4>(t, c, a.v, b.v, e.v, f.v, h); mul2_low_column<5>(t, c, a.v, b.v, e.v, f.v, h);
+  mul2_low_column<6>(t, c, a.v, b.v, e.v, f.v, h); mul2_low_column<7>(t, c, a.v, b.v, e.v, f.v, h);
+  u32 cy = 0;
+  r.v[0] = t[0];
+#pragma unroll
+  for (int i = 1; i < 8; i++) r.v[i] = addc(t[i], h[i - 1], cy);
+  const u64 T = c.lo + h[7] + cy + (((u64)h8 << 32) | (h8 ? C_LO : 0u));     // < 2^38
+  fold_top_fast(r.v, T);
+}
+
 // reduce a 16-word integer modulo p: lo + hi * 977 + (hi << 32), then fold what spills over 2^256
 ECGPU_HD void reduce16(FeK256& r, const u32* w) {
   u32 u[8];

@@ -29,7 +29,7 @@ ECGPU_HD void xyzz_add_mixed_raw(msm::Xyzz<C>& p, const typename C::Fe& x2, cons
   C::fe_sub(pp, pp, t); C::fe_sub(pp, pp, q); C::fe_sub(p.x, pp, q);   // X3 = R^2 - PPP - 2Q
   C::fe_mul(t, p.y, t);                                      // Y1 PPP
   C::fe_sub(q, q, p.x); C::fe_mul(q, r, q);                  // R (Q - X3)
-  C::fe_sub(p.y, q, t);
+  C::fe_sub(p.y, q, t);                                      // (the fused difference of products, C::fe_mul_sub2, costs this kernel registers: k256 signing 4.79 against 4.53 ms per 2^20)
 }
 
 // acc = k G for a scalar k < n (reduced by the caller), returned in the reference's homogeneous projective coordinates.

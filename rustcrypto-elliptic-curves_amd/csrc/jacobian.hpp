@@ -108,9 +108,8 @@ ECGPU_HD void add_mixed(Jac<C>& p, const typename C::Fe& x2, const typename C::F
   C::fe_mul(t, p.x, t);
   C::fe_sqr(u, r);
   C::fe_sub(u, u, h); C::fe_sub(u, u, t); C::fe_sub(p.x, u, t);
-  C::fe_sub(t, t, p.x); C::fe_mul(t, r, t);
-  C::fe_mul(h, p.y, h);
-  C::fe_sub(p.y, t, h);
+  C::fe_sub(t, t, p.x);
+  C::fe_mul_sub2(p.y, r, t, p.y, h);     // Y3 = R (V - X3) - Y1 HHH
 }
 
 // In-place p += (x2, y2) for p = (X1, Y1, 1) AFFINE and finite (the caller knows: the first addition after a set), (x2, y2) affine
@@ -132,9 +131,8 @@ ECGPU_HD void add_affine(Jac<C>& p, const typename C::Fe& x2, const typename C::
   C::fe_mul(t, p.x, t);
   C::fe_sqr(u, r);
   C::fe_sub(u, u, h); C::fe_sub(u, u, t); C::fe_sub(p.x, u, t);
-  C::fe_sub(t, t, p.x); C::fe_mul(t, r, t);
-  C::fe_mul(h, p.y, h);
-  C::fe_sub(p.y, t, h);
+  C::fe_sub(t, t, p.x);
+  C::fe_mul_sub2(p.y, r, t, p.y, h);     // Y3 = R (V - X3) - Y1 HHH
 }
 
 // Co-Z arithmetic for table chains P, 2P, 3P = 2P + P, .. (Meloni's additions with update): two points that share their

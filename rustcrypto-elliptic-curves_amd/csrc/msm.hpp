@@ -81,9 +81,8 @@ ECGPU_HD void xyzz_add_mixed(Xyzz<C>& p, const typename C::Fe& x2, const typenam
   C::fe_mul(p.zzz, p.zzz, t);                                // ZZZ3 = ZZZ1 PPP
   C::fe_sqr(pp, r);
   C::fe_sub(pp, pp, t); C::fe_sub(pp, pp, q); C::fe_sub(p.x, pp, q);   // X3 = R^2 - PPP - 2Q
-  C::fe_mul(t, p.y, t);                                      // Y1 PPP
-  C::fe_sub(q, q, p.x); C::fe_mul(q, r, q);                  // R (Q - X3)
-  C::fe_sub(p.y, q, t);
+  C::fe_sub(q, q, p.x);                                      // Q - X3
+  C::fe_mul_sub2(p.y, r, q, p.y, t);                         // Y3 = R (Q - X3) - Y1 PPP
 }
 // p += (x2, y2) for p = (X1, Y1, 1, 1) AFFINE and finite (the caller knows: the first addition after a set): 4M + 2S, ZZ3 = PP and
 // ZZZ3 = PPP fall out of the formula.  Same special cases by control flow.
@@ -110,9 +109,8 @@ ECGPU_HD void xyzz_add_affine(Xyzz<C>& p, const typename C::Fe& x2, const typena
   C::fe_mul(p.zzz, p.zz, pp);                                // ZZZ3 = PPP
   C::fe_sqr(t, r);
   C::fe_sub(t, t, p.zzz); C::fe_sub(t, t, q); C::fe_sub(p.x, t, q);    // X3 = R^2 - PPP - 2Q
-  C::fe_mul(t, p.y, p.zzz);                                  // Y1 PPP
-  C::fe_sub(q, q, p.x); C::fe_mul(q, r, q);                  // R (Q - X3)
-  C::fe_sub(p.y, q, t);
+  C::fe_sub(q, q, p.x);                                      // Q - X3
+  C::fe_mul_sub2(p.y, r, q, p.y, p.zzz);                     // Y3 = R (Q - X3) - Y1 PPP
 }
 // p += q, both in XYZZ coordinates (add-2008-s: 12M + 2S; a bucket left in pieces by the equal-run bucket sums is the sum of
 // its pieces).  Exceptional cases by control flow: either operand at infinity, the same point (doubling, through the

@@ -96,9 +96,15 @@ ECGPU_HD void jac_add_mixed(JacK256& p, const FeK256& x2, const FeK256& y2, FeK2
   mul(t, p.x, t);                            // V
   sqr(u, r);
   sub(u, u, h); sub(u, u, t); sub(p.x, u, t);    // X3 = R^2 - HHH - 2V
+#ifdef ECGPU_K256_NO_FUSED_Y3                    // A/B switch (tools/ab_round3f.sh): two multiplications, two reductions and a subtraction
   sub(t, t, p.x); mul(t, r, t);              // R (V - X3)
   mul(h, p.y, h);                            // Y1 HHH
   sub(p.y, t, h);
+#else
+  sub(t, t, p.x);                            // V - X3
+  neg(u, p.y);
+  mul_add2(p.y, r, t, u, h);                 // Y3 = R (V - X3) + (-Y1) HHH: both products on one set of columns, ONE reduction
+#endif
 }
 ECGPU_HD void jac_add_mixed(JacK256& r, const JacK256& p, const FeK256& x2, const FeK256& y2, FeK256* zr) {
   r = p;

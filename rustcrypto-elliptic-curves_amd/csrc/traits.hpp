@@ -34,6 +34,8 @@ struct CurveK256 {
   static ECGPU_HD bool fe_is_canonical(const Fe& a) { return k256::is_canonical(a); }
   static ECGPU_HD void fe_mul(Fe& r, const Fe& a, const Fe& b) { k256::mul(r, a, b); }
   static ECGPU_HD void fe_sqr(Fe& r, const Fe& a) { k256::sqr(r, a); }
+  // r = a b - e f: both products on one set of column accumulators, one reduction (fe_k256.hpp::mul_add2); r may alias any operand
+  static ECGPU_HD void fe_mul_sub2(Fe& r, const Fe& a, const Fe& b, const Fe& e, const Fe& f) { Fe n; k256::neg(n, e); k256::mul_add2(r, a, b, n, f); }
   static ECGPU_HD void fe_add(Fe& r, const Fe& a, const Fe& b) { k256::add(r, a, b); }
   static ECGPU_HD void fe_sub(Fe& r, const Fe& a, const Fe& b) { k256::sub(r, a, b); }
   static ECGPU_HD void fe_neg(Fe& r, const Fe& a) { k256::neg(r, a); }
@@ -92,6 +94,8 @@ struct CurveNist {
   static ECGPU_HD void fe_store(u32* be, const Fe& a) { u32 c[NW]; mont::from_mont<Mod>(c, a); words_store_be<NW>(be, c); }
   static ECGPU_HD void fe_mul(Fe& r, const Fe& a, const Fe& b) { mont::mul(r, a, b); }
   static ECGPU_HD void fe_sqr(Fe& r, const Fe& a) { mont::sqr(r, a); }
+  // r = a b - e f (two Montgomery multiplications: a fused form would need a second final subtraction and saves too little here); r may alias any operand
+  static ECGPU_HD void fe_mul_sub2(Fe& r, const Fe& a, const Fe& b, const Fe& e, const Fe& f) { Fe t, u; mont::mul(t, a, b); mont::mul(u, e, f); mont::sub(r, t, u); }
   static ECGPU_HD void fe_add(Fe& r, const Fe& a, const Fe& b) { mont::add(r, a, b); }
   static ECGPU_HD void fe_sub(Fe& r, const Fe& a, const Fe& b) { mont::sub(r, a, b); }
   static ECGPU_HD void fe_neg(Fe& r, const Fe& a) { mont::neg(r, a); }

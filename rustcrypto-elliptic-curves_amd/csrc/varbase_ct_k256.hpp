@@ -80,9 +80,9 @@ ECGPU_HD void k256_add_mixed_raw(JacK256& p, const FeK256& x2, const FeK256& y2,
   mul(t, p.x, t);
   sqr(u, r);
   sub(u, u, h); sub(u, u, t); sub(p.x, u, t);
-  sub(t, t, p.x); mul(t, r, t);
-  mul(h, p.y, h);
-  sub(p.y, t, h);
+  sub(t, t, p.x);
+  neg(u, p.y);
+  mul_add2(p.y, r, t, u, h);                 // Y3 = R (V - X3) + (-Y1) HHH, one reduction (fe_k256.hpp)
 }
 
 // acc += (qx, qy) for every digit; `zd` is all ones iff the digit is zero (acc is kept), `empty` all ones while acc is still O

@@ -11,6 +11,7 @@ static void store(uint8_t* b, const FeK256& f) { u32 w[8]; k256::to_be_words(w, 
 
 extern "C" {
 // op: 0 mul 1 sqr 2 add 3 sub 4 neg 5 inv 6 sqrt 7 mul_small(b[0..3] LE) 8 normalize-only 9/10/11 shl<1/2/3>
+//     12 mul_add2(x, y, y, x) = 2xy   13 mul_add2(x, y, ~x, ~y) (word-wise complements: raw operands up to 2^256 - 1)
 // raw=1: inputs are taken as raw 256-bit integers (possibly >= p) and the output is NOT normalised
 int ht_k256_fe_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int raw) {
   for (int i = 0; i < n; i++) {
@@ -29,6 +30,8 @@ int ht_k256_fe_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, int 
       case 9: k256::shl<1>(r, x); break;
       case 10: k256::shl<2>(r, x); break;
       case 11: { r = x; k256::shl<3>(r, r); break; }          // aliased
+      case 12: k256::mul_add2(r, x, y, y, x); break;
+      case 13: { FeK256 cx, cy; for (int w = 0; w < 8; w++) { cx.v[w] = ~x.v[w]; cy.v[w] = ~y.v[w]; } k256::mul_add2(r, x, y, cx, cy); break; }
       default: return -1;
     }
     if (!raw) k256::normalize(r, r);

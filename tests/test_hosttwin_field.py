@@ -47,6 +47,19 @@ def test_binary_ops_on_raw_inputs(op, fn):
         assert g % P == fn(x, y) % P
 
 
+def test_fused_sum_of_two_products():
+    """k256::mul_add2 (a b + e f with one reduction; the sum reaches 2^513, word 16 folds through C^2)."""
+    xs, ys = pairs()
+    M = 2**256 - 1
+    for op, fn in ((12, lambda x, y: 2 * x * y), (13, lambda x, y: x * y + (M - x) * (M - y))):
+        got = run(op, xs, ys)
+        for x, y, g in zip(xs, ys, got):
+            assert g == fn(x, y) % P, (op, hex(x), hex(y))
+        raw = run(op, xs, ys, raw=1)
+        for x, y, g in zip(xs, ys, raw):
+            assert g < 2**256 and g % P == fn(x, y) % P
+
+
 def test_unary_ops():
     rng = random.Random(5)
     xs = EDGE + [rng.randrange(2**256) for _ in range(1500)]

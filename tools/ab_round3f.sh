@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-3 A/B measurements, sixth set: Y3 of the secp256k1 mixed addition as ONE fused sum of two products (k256::mul_add2:
+# both products on the same column accumulators, one reduction) against two multiplications and a subtraction
+# (-DECGPU_K256_NO_FUSED_Y3).  Both libraries are built from the same tree; selected through ECGPU_LIB.
+#   gpurun --timeout 900 -- 'mkdir -p gpurun_out/r3 && bash tools/ab_round3f.sh > gpurun_out/r3/ab_f.txt 2>&1'
+cd "${GRAFT_REPO_ROOT:-.}"
+PK=$PWD/rustcrypto-elliptic-curves_amd
+B="--no-cpu-baseline --no-other-configs --steps 5 --warmup 1"
+line() { python -c 'import sys, json
+for l in sys.stdin:
+    if l.startswith("{"):
+        d = json.loads(l); print("   ", d["config"]["workload"][:40], "ms_per_step", round(d["ms_per_step"], 3), "value", "%.4g" % d["value"], "parity", d["parity_ok"])'; }
+for rep in 1 2 3; do
+  for v in ${VARIANTS:-fused nofused}; do
+    export ECGPU_LIB=$PK/lib_exp/libecgpu_$v.so
+    echo "#### k256 variable base 2^24 (headline), library: $v (pass $rep)"
+    timeout -k 10 200 python bench.py $B --workload k256_varbase 2>/dev/null | line
+  done
+done
+for v in ${VARIANTS:-fused nofused}; do
+  export ECGPU_LIB=$PK/lib_exp/libecgpu_$v.so
+  echo "#### k256 secret-scalar variable base 2^22, two-term linear combination 2^22, library: $v"
+  timeout -k 10 200 python tools/ct_varbase_bench.py 22 k256 2>&1 | grep -v amdgpu.ids
+  timeout -k 10 120 python tools/gpu_quick.py k256 22 lincomb2 2>&1 | tail -1
+done
