@@ -100,7 +100,7 @@ enum {
   ECGPU_PUBLIC_SCALARS = 4u,
   /* ecgpu_mul_batch / ecgpu_lincomb_batch: the scalars are secret and only the group element is wanted (key generation:
    * PublicKey::from_secret_scalar is d G).  With points == NULL the multiplication runs on the constant-time fixed-base
-   * kernel signing uses (every table entry read, one masked Jacobian addition per window; the result is the same point, not the reference's
+   * kernel signing uses (every table entry read, one masked XYZZ mixed addition per window; the result is the same point, not the reference's
    * (X, Y, Z)); with a variable base point (ECDH: elliptic_curve::ecdh::diffie_hellman) dedicated constant-time
    * kernels run.  P-256 / P-384 (csrc/varbase_ct.hpp): signed 4-bit digits of min(k, n - k) by branch-free recoding, a masked scan
    * over all eight entries of a per-lane affine table, Jacobian doublings and a mixed addition for every digit whose two special
@@ -290,7 +290,7 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* prehash, 
  * y_is_odd(R) | x_is_reduced << 1; ok[i] = 0 (and a zero signature) when d or k is outside [1, n-1]
  * or r = 0 or s = 0, where the reference returns Err.
  * The nonce is secret, so k G runs constant-time: by default on a fixed-base kernel that reads every entry of its
- * 5-bit-window table and keeps the digit's one by masks, one Jacobian mixed addition per window whose special operands (empty
+ * 5-bit-window table and keeps the digit's one by masks, one XYZZ mixed addition (8M + 2S) per window whose special operands (empty
  * accumulator, zero digit) are masks and which the bounds on the digits keep off its exceptional cases (csrc/fixedbase_ct.hpp) - 6-7x the
  * speed of the reference schedule on P-256 / P-384, whose mul_by_generator is the generic variable-base
  * multiplication); ECGPU_EXACT_REFERENCE in `flags` selects the reference's own mul_by_generator schedule (constant-time
