@@ -25,9 +25,11 @@ struct ecgpu_ctx {
   static constexpr int NSTAGE = 18;          // 6 for whole-batch staging + 2 pipeline slots x 6 arguments
   void* stage[NSTAGE] = {};
   size_t stage_cap[NSTAGE] = {};
-  // second stream + events of the chunked host-buffer pipeline (ecgpu.hip: host_pipeline)
+  // download and upload streams + events of the chunked host-buffer pipeline (ecgpu.hip: host_pipeline)
   hipStream_t copy_stream = nullptr;
+  hipStream_t up_stream = nullptr;
   hipEvent_t ev_kernel[2] = {nullptr, nullptr};
+  hipEvent_t ev_up[2] = {nullptr, nullptr};
   // precomputed generator tables, one per curve, built on first use
   void* gen_table[3] = {nullptr, nullptr, nullptr};
   // fixed-base tables of the throughput schedule (fixedbase.hpp)
