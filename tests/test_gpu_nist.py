@@ -322,6 +322,7 @@ def test_fixed_base_wide_tables_ragged_sizes(ctx, cn, cid):
     """The wide fixed-base kernels keep up to 64 results per lane for one shared inversion: batch sizes that are not
     multiples of anything (2^18 + 333 -> 16-bit windows, 2^21 + 777 -> 20-bit windows), head and tail against the C oracle."""
     import torch
+    import ecgpu
     cv = ctx.curve(cn)
     nb = cv.nb
     for n in ((1 << 18) + 333, (1 << 21) + 777):
@@ -329,13 +330,33 @@ def test_fixed_base_wide_tables_ragged_sizes(ctx, cn, cid):
         d_o = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
         d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
         cv.synth_scalars_device(d_s, n, synth.SEED, 99 + n)
+        idx = np.concatenate([np.arange(0, 200), np.arange(n - 200, n), np.arange(1000, n, n // 97)])
+        # identity results in every slot of a lane's shared inversion, not only the first (a lane's results are strided by the
+        # grid size): zero scalars and n itself at sampled positions across the whole batch
+        ctx.synchronize()
+        s_all = d_s.cpu().numpy()
+        c = M.CURVES[cn]
+        for q, i in enumerate(idx[5::7]):
+            s_all[i] = 0 if q % 2 == 0 else np.frombuffer(int(c.n).to_bytes(nb, "big"), dtype=np.uint8)
+        d_s.copy_(torch.from_numpy(s_all))
         cv.mul_device(d_s, None, d_o, n, d_out_inf=d_i)
         ctx.synchronize()
-        idx = np.concatenate([np.arange(0, 200), np.arange(n - 200, n), np.arange(1000, n, n // 97)])
-        s = d_s.cpu().numpy()[idx].copy()
+        s = s_all[idx].copy()
         want = CO.lincomb_batch(cid, s, None, threads=4)
         got = np.concatenate([d_o.cpu().numpy()[idx], d_i.cpu().numpy()[idx][:, None]], axis=1)
         assert bytes(got) == bytes(want), n
+        assert int(d_i.cpu().numpy()[idx[5::7]].min()) == 1            # the planted scalars gave the identity
+        # the same batch with projective output: (x : y : 1), identity (0 : 1 : 0)
+        d_p = torch.empty((n, 3 * nb), dtype=torch.uint8, device="cuda")
+        cv.mul_device(d_s, None, d_p, n, out_format=ecgpu.PROJECTIVE)
+        ctx.synchronize()
+        pr = d_p.cpu().numpy()[idx]
+        one = np.zeros(nb, dtype=np.uint8); one[-1] = 1
+        for j in range(len(idx)):
+            if want[j, 2 * nb]:
+                assert not pr[j, :nb].any() and bytes(pr[j, nb:2 * nb]) == bytes(one) and not pr[j, 2 * nb:].any()
+            else:
+                assert bytes(pr[j, :2 * nb]) == bytes(want[j, :2 * nb]) and bytes(pr[j, 2 * nb:]) == bytes(one)
 
 
 @pytest.mark.parametrize("cn,cid", [("p256", 1), ("p384", 2)])

@@ -1,4 +1,8 @@
+#!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
+# Round-3 A/B measurements, sixth set (second half): the fused difference of products in the XYZZ additions (MSM bucket sums, signing) and in the
+# constant-time secp256k1 variable-base kernel.  "fused" = the library of tools/ab_round3f.sh (only the Jacobian mixed addition of the headline
+# kernel fused), default = the in-tree build.   gpurun --timeout 900 -- 'bash tools/ab_round3g.sh > gpurun_out/r3/ab_g.txt 2>&1'
 PK=$PWD/rustcrypto-elliptic-curves_amd
 B="--no-cpu-baseline --no-other-configs --steps 10 --warmup 2"
 line() { python -c 'import sys, json
