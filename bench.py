@@ -59,7 +59,10 @@ MAC_CONV = {"k256": 64, "p256": 64, "p384": 144}
 MAC_ISSUED = {"k256": (72, 53), "p256": (88, 88), "p384": (168, 126)}
 # secp256k1 mixed additions compute Y3 = R (V - X3) - Y1 HHH as ONE fused difference of two products (round 3: k256::mul_add2,
 # one reduction for both): 8 fold products less per addition in the ISSUED count; the algorithmic count (two multiplications) stays.
+# The secp256k1 doubling does the same with Y3 = E (D - X3) - 8 B^2: the squaring B^2 becomes the second product of the fused form (72 issued
+# products instead of 53, no fold of its own: + 19 - 8 = + 11 per doubling; FUSED_DBL).
 FUSED_PAIRS = {"k256_varbase_fast": 66 * 15 / 16, "k256_msm": 14, "k256_ecdsa_verify": 66 * 15 / 16 + 11}
+FUSED_DBL = {"k256_varbase_fast": 128, "k256_ecdsa_verify": 128}
 
 WORK = {
     # reference schedule: 128 doublings (6M+2S) + 80 complete additions (12M) + to_affine (255S + 17M)
@@ -517,7 +520,7 @@ def roofline_for(name, res, schedule, peak_meas, pair_meas, world=1):
     modmul = m_cnt + s_cnt
     mac_conv = modmul * MAC_CONV[wl["curve"]]
     iss_m, iss_s = MAC_ISSUED[wl["curve"]]
-    mac_issued = m_cnt * iss_m + s_cnt * iss_s - 8 * FUSED_PAIRS.get(key, 0)
+    mac_issued = m_cnt * iss_m + s_cnt * iss_s - 8 * FUSED_PAIRS.get(key, 0) + 11 * FUSED_DBL.get(key, 0)
     kernel_s = res["kernel_ms"] / 1e3
     n = res["n"]
     achieved = n * mac_conv / kernel_s / 1e12
