@@ -165,11 +165,27 @@ int ecgpu_fb_table_bytes(ecgpu_ctx* ctx, int curve, size_t* bytes, int* widest_w
 const char* ecgpu_version(void);
 /* NB for a curve (32 / 32 / 48), 0 for an unknown curve. */
 size_t ecgpu_field_bytes(int curve);
-/* Page-locked host memory for ECGPU_MEM_HOST batches.  Host-buffer calls work with any memory; from pageable memory
- * the transfers run at ~10 GB/s, from these buffers at PCIe rate, and batches of 2^21 elements or more are streamed
- * through the device in chunks with upload, kernels and download overlapped. */
+/* Page-locked host memory for ECGPU_MEM_HOST batches.  Host-buffer calls work with any memory.  Batches of 2^21 elements or
+ * more are streamed through the device in chunks with upload, kernels and download overlapped (chunk sizes grow from an eighth of
+ * a kernel pass to a whole pass and the last chunk is small again, so fill and drain are short); page-locked buffers (these, or
+ * memory the caller registered with hipHostRegister) are read and written by DMA directly, pageable ones are copied through a small
+ * pool of page-locked bounce buffers by helper threads.  secp256k1 variable base, 2^24 pairs: see DESIGN.md section 7 / bench.py
+ * `host_io` for the PCIe-inclusive rates.  ecgpu_msm from host memory streams its terms the same way in parts of 2^23. */
 int ecgpu_host_alloc(ecgpu_ctx* ctx, size_t bytes, void** out);
 int ecgpu_host_free(ecgpu_ctx* ctx, void* p);
+
+/* How a host-buffer batch of n elements is cut into chunks when one whole pass of its kernel takes pass_units elements
+ * (clamped to 2^20 .. 2^23): sizes grow from pass / 8 to pass, the last chunk is at most pass / 8.  Fills sizes[0 .. cap) and
+ * returns the number of chunks; needs no device.  (Batches below 2^21 elements are staged whole.) */
+int ecgpu_host_chunk_schedule(size_t n, size_t pass_units, size_t* sizes, size_t cap);
+
+/* Diagnostic: size and contents of a context's grow-only device workspaces (which = 0: per-lane table workspace of the
+ * variable-base kernels, 1: intermediate scalars / points of the ECDSA / ECDH pipelines, 2: MSM workspace, 16 + i: staging slot i of
+ * host-buffer calls; 16 + 6 + 6 s + a is argument a of pipeline slot s).  *bytes = the workspace's size (0 if it does not exist
+ * yet); if host_copy is not NULL the first min(cap, size) bytes are copied into it after the context's stream has drained.
+ * For audits of secret hygiene: the tests read the workspaces back after secret-scalar calls and check that no result, prefix
+ * product or staged secret is left (tests/test_gpu_ct_varbase.py). */
+int ecgpu_debug_workspace(ecgpu_ctx* ctx, int which, void* host_copy, size_t cap, size_t* bytes);
 
 /* HIP-event timer on the context's stream: bracket launches, read milliseconds. */
 int ecgpu_timer_start(ecgpu_ctx* ctx);

@@ -110,7 +110,11 @@ struct CurveOps {
     } tks, txy, ttab;
     // a table that does not fit - the context's budget or the device's memory - is not an error: the caller falls back to
     // the next narrower width
-    if (c->opt[ECGPU_OPT_FB_MEMORY_BUDGET] > 0 && c->fb_bytes[C::ID] + total * sizeof(AffEntry<C>) > (size_t)c->opt[ECGPU_OPT_FB_MEMORY_BUDGET]) return FB_NOMEM;
+    // (the budget is about the OPTIONAL wide tables: the 5-bit table of the constant-time kernel behind signing and key generation is
+    // 53-80 KB and mandatory, like the 8-bit base table - neither is ever refused on the budget's account, though both count towards it)
+    if (WB != fb::CT_WB && c->opt[ECGPU_OPT_FB_MEMORY_BUDGET] > 0 &&
+        c->fb_bytes[C::ID] + total * sizeof(AffEntry<C>) > (size_t)c->opt[ECGPU_OPT_FB_MEMORY_BUDGET])
+      return FB_NOMEM;
     {
       hipError_t e = hipMalloc(&tks.p, chunk * C::NB);
       if (e == hipSuccess) e = hipMalloc(&txy.p, chunk * 2 * C::NB);
@@ -182,7 +186,7 @@ struct CurveOps {
   // k G for secret scalars: constant-time fixed-base kernel (fixedbase.hpp), one inversion per 8 results
   static int mul_gen_ct(ecgpu_ctx* c, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
     int rc = ensure_fb_wide_table<fb::CT_WB>(c, &c->fbct_table[C::ID]);
-    if (rc == FB_NOMEM) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "out of device memory for the 5-bit generator table");
+    if (rc == FB_NOMEM) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "hipMalloc failed (out of device memory) for the 5-bit generator table of the constant-time kernel");
     if (rc) return rc;
     constexpr int WAVES = FBCT_WAVES(C);
     hipLaunchKernelGGL((fb::mul_ct_kernel<C, 8, WAVES>), dim3(ecgpu_grid_for(c, n, WAVES)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)c->fbct_table[C::ID], out,
@@ -233,6 +237,16 @@ struct CurveOps {
     return 0;
   }
   static int msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt);
+  // resident lanes at `waves` workgroups of 256 per CU (what ecgpu_grid_for caps a grid at)
+  static size_t resident_lanes(const ecgpu_ctx* c, int waves) { return (size_t)c->num_cus * (size_t)waves * 256; }
+  // units per whole pass of the variable-base kernels (specialised in ops_*.hip, where their sub-batch sizes are)
+  static size_t pass_units_points(const ecgpu_ctx* c, size_t terms, unsigned flags);
+  static size_t pass_units(const ecgpu_ctx* c, int has_points, size_t terms, unsigned flags) {
+    if (has_points) return pass_units_points(c, terms, flags);
+    if ((flags & ECGPU_SECRET_SCALARS) && !(flags & ECGPU_EXACT_REFERENCE)) return resident_lanes(c, FBCT_WAVES(C)) * 8;   // fb::mul_ct_kernel<C, 8, ..>
+    if (flags & ECGPU_EXACT_REFERENCE) return resident_lanes(c, 4);
+    return resident_lanes(c, 4) * (size_t)(FB_BATCH);                                                                    // fb::mul_wide_kernel<C, .., FB_BATCH, 4>
+  }
   static int point_eq(ecgpu_ctx* c, const u32* p, const u32* q, uint8_t* eq, size_t n) {
     hipLaunchKernelGGL((point_eq_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, p, q, eq, n);
     HIPCHK(c, hipGetLastError());
@@ -374,16 +388,22 @@ struct CurveOps {
   // ECDH (ecdh_kernels.hpp): input checks, the secret-scalar multiplication (constant-time kernel where the curve has
   // one, the reference schedule otherwise), x of the product
   static int ecdh(ecgpu_ctx* c, const u32* d, const u32* q, u32* shared_x, uint8_t* ok, size_t n) {
-    int rc = ecdsa_reserve(c, al256(n * 2 * C::NB));
+    const size_t sz_p = al256(n * 2 * C::NB);
+    int rc = ecdsa_reserve(c, 2 * sz_p);
     if (rc) return rc;
     u32* prod = (u32*)c->ecdsa_ws;
-    hipLaunchKernelGGL((ecdh::prep_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, d, q, ok, n);
+    u32* q_sane = (u32*)((char*)c->ecdsa_ws + sz_p);
+    // the products are secrets of the same rank as the shared values handed back: they do not stay in the workspace, whichever way
+    // this function is left (the constant-time kernels clear what they park in the table workspace themselves)
+    struct ProdWipe {
+      ecgpu_ctx* c; void* p; size_t b;
+      ~ProdWipe() { (void)hipMemsetAsync(p, 0, b, c->stream); }
+    } prod_wipe{c, prod, n * 2 * C::NB};
+    hipLaunchKernelGGL((ecdh::prep_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, d, q, q_sane, ok, n);
     HIPCHK(c, hipGetLastError());
-    if ((rc = lincomb(c, d, q, FMT_AFFINE, 1, prod, FMT_AFFINE, nullptr, n, (unsigned)ECGPU_SECRET_SCALARS))) return rc;
+    if ((rc = lincomb(c, d, q_sane, FMT_AFFINE, 1, prod, FMT_AFFINE, nullptr, n, (unsigned)ECGPU_SECRET_SCALARS))) return rc;
     hipLaunchKernelGGL((ecdh::finish_kernel<C>), dim3(ecgpu_grid_for(c, n, 8)), dim3(256), 0, c->stream, (const u32*)prod, (const uint8_t*)ok, shared_x, n);
     HIPCHK(c, hipGetLastError());
-    // the products are secrets of the same rank as the shared values handed back: they do not stay in the workspace
-    HIPCHK(c, hipMemsetAsync(prod, 0, n * 2 * C::NB, c->stream));
     return 0;
   }
   static int ecdsa_sign(ecgpu_ctx* c, const u32* d, const u32* k, const u32* z, u32* sig, uint8_t* recid, uint8_t* ok, size_t n,
@@ -407,7 +427,8 @@ struct CurveOps {
   }
   static const ecgpu_curve_ops* table() {
     static const ecgpu_curve_ops t = {field_op, point_op, point_eq, normalize, lincomb, msm, validate_scalars, validate_points,
-                                      decompress, synth_scalars, synth_points, to_bytes, from_bytes, sec1_encode, sec1_decode, ecdsa_verify, h2c_map, ecdsa_recover, schnorr_verify, ecdsa_sign, ecdh};
+                                      decompress, synth_scalars, synth_points, to_bytes, from_bytes, sec1_encode, sec1_decode, ecdsa_verify, h2c_map, ecdsa_recover, schnorr_verify, ecdsa_sign, ecdh,
+                                      pass_units};
     return &t;
   }
 };

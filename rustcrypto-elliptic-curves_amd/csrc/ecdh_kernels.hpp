@@ -10,13 +10,26 @@ namespace ecgpu {
 namespace ecdh {
 
 // ok[i] = NonZeroScalar::from_repr(secret[i]).is_some() && PublicKey::from_affine(pub[i]).is_ok()
+// pubs_sane[i] = pub[i] where ok, else the generator: the constant-time kernel's exception-free argument (varbase_ct.hpp) is stated for
+// points of the group, so only such points reach it - a key that is off the curve never enters the multiplication (its result is
+// discarded by finish_kernel anyway).  The choice depends on the PUBLIC key only.
 template <class C>
-__global__ void __launch_bounds__(256) prep_kernel(const u32* secrets, const u32* pubs, uint8_t* ok, size_t n) {
+__global__ void __launch_bounds__(256) prep_kernel(const u32* secrets, const u32* pubs, u32* pubs_sane, uint8_t* ok, size_t n) {
   using O = OrderOf<C>;
   ECGPU_GRID_STRIDE(i, n) {
     u32 d[O::L];
     ecdsa::load_be<O::L>(d, secrets + i * C::NW);
-    ok[i] = (ecdsa::in_range<O>(d) && ecdsa::public_key_ok<C>(pubs + i * 2 * C::NW)) ? 1 : 0;
+    const bool key_ok = ecdsa::public_key_ok<C>(pubs + i * 2 * C::NW);
+    ok[i] = (ecdsa::in_range<O>(d) && key_ok) ? 1 : 0;
+    if (key_ok) {
+#pragma unroll
+      for (int w = 0; w < 2 * C::NW; w++) pubs_sane[i * 2 * C::NW + w] = pubs[i * 2 * C::NW + w];
+    } else {
+      typename C::Pt g;
+      C::pt_generator(g);
+      C::fe_store(pubs_sane + i * 2 * C::NW, g.x);
+      C::fe_store(pubs_sane + i * 2 * C::NW + C::NW, g.y);
+    }
   }
 }
 // shared[i] = x of the product, zeros where ok[i] = 0

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "ecgpu_internal.hpp"
+#include "host_pipe.hpp"
 
 static int stage_reserve(ecgpu_ctx* c, int slot, size_t bytes) {
   if (bytes <= c->stage_cap[slot]) return 0;
@@ -58,99 +59,22 @@ static int finish_host(ecgpu_ctx* c, int mem) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Host-buffer calls on large batches: chunks of PIPE_CHUNK units flow through two device slots so that the
-// upload of chunk i+1, the kernels of chunk i and the download of chunk i-1 overlap: uploads run on their own stream (the
-// chunk's kernels wait for its event; until late in round 3 they were queued on the compute stream itself, behind the previous
-// chunk's kernels, and only the downloads overlapped: 8.5 x 10^7 /s from page-locked buffers against 1.2 x 10^8 device-resident).
-// Pageable host memory makes hipMemcpyAsync block its caller, hence the download runs on a helper thread (own stream, ordered
-// after the chunk's kernels by an event); the calling thread uploads and launches.  Element i of every argument must depend
-// only on element i of the inputs (true for every batch entry point that uses this).
+// Host-buffer calls on large batches stream through the device in chunks (host_pipe.hpp): batches of PIPE_MIN units and more.
+// `pass` is the number of units that gives every resident lane of the dominant kernel its full sub-batch (the curve's
+// ops->pass_units): chunks grow from pass / 8 to pass and the last one is small again.
 // ---------------------------------------------------------------------------------------------
-static constexpr size_t PIPE_CHUNK = (size_t)1 << 20;
-static constexpr int PIPE_MAXARGS = 6;
-struct PipeArg {
-  const void* in;      // host input  (or nullptr)
-  void* out;           // host output (or nullptr)
-  size_t unit;         // bytes per batch element
-};
+static constexpr size_t PIPE_MIN = (size_t)1 << 21;
+// one multi-scalar multiplication from host memory: sums of MSM_PIPE_MIN terms and more are cut into parts of MSM_PIPE_PART terms
+// (a part is one slab of either window width: msm_kernels.hpp Geo<CB>::SLAB_TERMS >= 2^23)
+static constexpr size_t MSM_PIPE_MIN = (size_t)1 << 22, MSM_PIPE_PART = (size_t)1 << 23;
+using PipeArg = hostpipe::Arg;
+extern "C" int ecgpu_host_chunk_schedule(size_t n, size_t pass_units, size_t* sizes, size_t cap);
 template <class Launch>
-static int host_pipeline(ecgpu_ctx* c, const PipeArg* args, int nargs, size_t n, Launch launch) {
-  if (nargs > PIPE_MAXARGS) return ecgpu_set_err(c, ECGPU_ERR_ARG, "host_pipeline: too many arguments");
-  if (!c->copy_stream) {
-    HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
-      HIPCHK(c, hipEventCreateWithFlags(&c->ev_kernel[i], hipEventDisableTiming));
-      HIPCHK(c, hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
-    }
-  }
-  for (int s = 0; s < 2; s++)
-    for (int a = 0; a < nargs; a++) {
-      if (!args[a].in && !args[a].out) continue;
-      int rc = stage_reserve(c, 6 + s * PIPE_MAXARGS + a, PIPE_CHUNK * args[a].unit);
-      if (rc) return rc;
-    }
-  const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
-  std::mutex mu;
-  std::condition_variable cv;
-  size_t launched = 0, drained = 0;        // chunks whose kernels are enqueued / whose outputs are back on the host
-  hipError_t copy_err = hipSuccess;
-  bool abort_flag = false;
-  std::thread drain([&] {
-    (void)hipSetDevice(c->device);
-    for (size_t ci = 0; ci < nchunks; ci++) {
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return launched > ci || abort_flag; });
-        if (abort_flag) return;
-      }
-      const int slot = (int)(ci & 1);
-      const size_t lo = ci * PIPE_CHUNK, cnt = (n - lo < PIPE_CHUNK) ? n - lo : PIPE_CHUNK;
-      hipError_t e = hipStreamWaitEvent(c->copy_stream, c->ev_kernel[slot], 0);
-      for (int a = 0; a < nargs && e == hipSuccess; a++)
-        if (args[a].out)
-          e = hipMemcpyAsync((char*)args[a].out + lo * args[a].unit, c->stage[6 + slot * PIPE_MAXARGS + a], cnt * args[a].unit,
-                             hipMemcpyDeviceToHost, c->copy_stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
-      std::lock_guard<std::mutex> lk(mu);
-      if (e != hipSuccess && copy_err == hipSuccess) copy_err = e;
-      drained = ci + 1;
-      cv.notify_all();
-    }
-  });
-  int rc = 0;
-  hipError_t up_err = hipSuccess;
-  for (size_t ci = 0; ci < nchunks && rc == 0 && up_err == hipSuccess; ci++) {
-    const int slot = (int)(ci & 1);
-    if (ci >= 2) {                         // the slot is free once chunk ci-2 has been downloaded
-      std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return drained + 2 > ci; });
-    }
-    const size_t lo = ci * PIPE_CHUNK, cnt = (n - lo < PIPE_CHUNK) ? n - lo : PIPE_CHUNK;
-    void* dev[PIPE_MAXARGS];
-    for (int a = 0; a < nargs; a++) {
-      dev[a] = (args[a].in || args[a].out) ? c->stage[6 + slot * PIPE_MAXARGS + a] : nullptr;
-      if (args[a].in && up_err == hipSuccess)
-        up_err = hipMemcpyAsync(dev[a], (const char*)args[a].in + lo * args[a].unit, cnt * args[a].unit, hipMemcpyHostToDevice, c->up_stream);
-    }
-    // the chunk's kernels start when its inputs have arrived; the slot itself is free (chunk ci-2 has been drained, see above)
-    if (up_err == hipSuccess) up_err = hipEventRecord(c->ev_up[slot], c->up_stream);
-    if (up_err == hipSuccess) up_err = hipStreamWaitEvent(c->stream, c->ev_up[slot], 0);
-    if (up_err == hipSuccess) rc = launch(dev, cnt);
-    if (rc == 0 && up_err == hipSuccess) up_err = hipEventRecord(c->ev_kernel[slot], c->stream);
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      if (rc != 0 || up_err != hipSuccess) abort_flag = true; else launched = ci + 1;
-      cv.notify_all();
-    }
-  }
-  drain.join();
-  (void)hipStreamSynchronize(c->up_stream);          // an aborted run may still have an upload in flight
-  (void)hipStreamSynchronize(c->stream);
-  if (rc) return rc;
-  if (up_err != hipSuccess) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "host pipeline upload: %s", hipGetErrorString(up_err));
-  if (copy_err != hipSuccess) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "host pipeline download: %s", hipGetErrorString(copy_err));
-  return 0;
+static int host_pipeline(ecgpu_ctx* c, const PipeArg* args, int nargs, size_t n, size_t pass, bool secret, Launch launch) {
+  std::vector<size_t> sizes((size_t)ecgpu_host_chunk_schedule(n, pass, nullptr, 0));
+  (void)ecgpu_host_chunk_schedule(n, pass, sizes.data(), sizes.size());
+  return hostpipe::run(c, args, nargs, sizes, secret, [&](int slot, size_t bytes) { return stage_reserve(c, slot, bytes); },
+                       [&](void** d, size_t cnt, size_t) { return launch(d, cnt); });
 }
 
 static const ecgpu_curve_ops* ops_for(int curve) {
@@ -171,7 +95,7 @@ static const ecgpu_curve_ops* ops_for(int curve) {
 
 extern "C" {
 
-const char* ecgpu_version(void) { return "ecgpu 0.1 (gfx950)"; }
+const char* ecgpu_version(void) { return "ecgpu 0.4 (gfx950)"; }
 
 size_t ecgpu_field_bytes(int curve) {
   switch (curve) {
@@ -214,8 +138,16 @@ void ecgpu_destroy(ecgpu_ctx* c) {
       (void)hipMemset(c->stage[i], 0, c->stage_cap[i]);
       (void)hipFree(c->stage[i]);
     }
-  for (int i = 0; i < 2; i++) if (c->ev_kernel[i]) (void)hipEventDestroy(c->ev_kernel[i]);
-  for (int i = 0; i < 2; i++) if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
+  for (int i = 0; i < ecgpu_ctx::PIPE_NSLOT; i++) {
+    if (c->ev_kernel[i]) (void)hipEventDestroy(c->ev_kernel[i]);
+    if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
+    if (c->ev_down[i]) (void)hipEventDestroy(c->ev_down[i]);
+  }
+  for (int d = 0; d < 2; d++)
+    for (int w = 0; w < ecgpu_ctx::PIPE_NWORK; w++) {
+      if (c->bounce[d][w]) { memset(c->bounce[d][w], 0, ecgpu_ctx::PIPE_BOUNCE); (void)hipHostFree(c->bounce[d][w]); }
+      if (c->ev_bounce[d][w]) (void)hipEventDestroy(c->ev_bounce[d][w]);
+    }
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
   for (int i = 0; i < 3; i++) if (c->gen_table[i]) (void)hipFree(c->gen_table[i]);
@@ -310,6 +242,34 @@ int ecgpu_fb_table_bytes(ecgpu_ctx* c, int curve, size_t* bytes, int* widest) {
   std::lock_guard<std::mutex> lk(c->mu);
   if (bytes) *bytes = c->fb_bytes[curve];
   if (widest) *widest = c->fb_widest[curve];
+  return ECGPU_OK;
+}
+
+int ecgpu_host_chunk_schedule(size_t n, size_t pass_units, size_t* sizes, size_t cap) {
+  size_t pass = pass_units;
+  if (pass > ((size_t)1 << 23)) pass = (size_t)1 << 23;
+  if (pass < ((size_t)1 << 20)) pass = (size_t)1 << 20;
+  const std::vector<size_t> v = hostpipe::schedule(n, pass / 8, pass, pass / 8, pass / 16);
+  for (size_t i = 0; i < v.size() && i < cap && sizes; i++) sizes[i] = v[i];
+  return (int)v.size();
+}
+
+int ecgpu_debug_workspace(ecgpu_ctx* c, int which, void* host_copy, size_t cap, size_t* bytes) {
+  if (!c || !bytes) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  void* p = nullptr;
+  size_t sz = 0;
+  if (which == 0) { p = c->tab_ws; sz = c->tab_ws_cap; }
+  else if (which == 1) { p = c->ecdsa_ws; sz = c->ecdsa_ws_cap; }
+  else if (which == 2) { p = c->msm_ws; sz = c->msm_ws_cap; }
+  else if (which >= 16 && which < 16 + ecgpu_ctx::NSTAGE) { p = c->stage[which - 16]; sz = c->stage_cap[which - 16]; }
+  else return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_debug_workspace: unknown workspace %d", which);
+  *bytes = sz;
+  if (host_copy && p && sz && cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(host_copy, p, cap < sz ? cap : sz, hipMemcpyDeviceToHost));
+  }
   return ECGPU_OK;
 }
 
@@ -420,11 +380,14 @@ int ecgpu_batch_normalize(ecgpu_ctx* c, int curve, const uint8_t* p, uint8_t* ou
 // bytes this call staged in its slots on EVERY exit path, the error returns included, and waits for the clearing.
 struct SecretWipe {
   ecgpu_ctx* c;
-  int slot[4];
-  size_t bytes[4];
+  static constexpr int CAP = 3 * ecgpu_ctx::PIPE_NSLOT + 3;
+  int slot[CAP];
+  size_t bytes[CAP];
   int cnt = 0;
   explicit SecretWipe(ecgpu_ctx* ctx) : c(ctx) {}
-  void arm(int s, size_t b) { if (cnt < 4) { slot[cnt] = s; bytes[cnt] = b; cnt++; } }
+  void arm(int s, size_t b) { if (cnt < CAP) { slot[cnt] = s; bytes[cnt] = b; cnt++; } }
+  // argument `a` of every pipeline slot, whole capacity (the chunk sizes vary)
+  void arm_pipeline(int a) { for (int sl = 0; sl < ecgpu_ctx::PIPE_NSLOT; sl++) arm(hostpipe::stage_index(sl, a), (size_t)-1); }
   ~SecretWipe() {
     if (!cnt) return;
     for (int i = 0; i < cnt; i++) {
@@ -448,11 +411,11 @@ static int lincomb_impl(ecgpu_ctx* c, int curve, const uint8_t* scalars, const u
   // the reference schedule is the one meant for secret scalars: their staged copies do not outlive the call
   const bool secret = (flags & (ECGPU_EXACT_REFERENCE | ECGPU_SECRET_SCALARS)) != 0;
   SecretWipe wipe(c);
-  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
-    if (secret) for (int sl = 0; sl < 2; sl++) wipe.arm(6 + sl * PIPE_MAXARGS, PIPE_CHUNK * terms * nb);
+  if (mem == ECGPU_MEM_HOST && n >= PIPE_MIN) {
+    if (secret) { wipe.arm_pipeline(0); if (flags & ECGPU_SECRET_SCALARS) wipe.arm_pipeline(2); }    // the scalars; for a secret scalar the product is a secret too
     const PipeArg args[5] = {{scalars, nullptr, terms * nb}, {points, nullptr, points ? terms * pin : 0}, {nullptr, out, pout},
                              {nullptr, out_fmt == ECGPU_PT_AFFINE ? out_inf : nullptr, 1}, {nullptr, scalar_ok, 1}};
-    int rc = host_pipeline(c, args, 5, n, [&](void** d, size_t cnt) {
+    int rc = host_pipeline(c, args, 5, n, ops->pass_units(c, points != nullptr, terms, flags), secret, [&](void** d, size_t cnt) {
       if (d[4]) {
         int r2 = ops->validate_scalars(c, (const uint32_t*)d[0], (uint8_t*)d[4], cnt, terms);
         if (r2) return r2;
@@ -463,7 +426,7 @@ static int lincomb_impl(ecgpu_ctx* c, int curve, const uint8_t* scalars, const u
   }
   Buf bs, bp, bo, bi, bk;
   int rc;
-  if (secret && mem == ECGPU_MEM_HOST) wipe.arm(0, n * terms * nb);
+  if (secret && mem == ECGPU_MEM_HOST) { wipe.arm(0, n * terms * nb); if (flags & ECGPU_SECRET_SCALARS) wipe.arm(2, n * pout); }
   if ((rc = buf_in(c, bs, 0, scalars, n * terms * nb, mem))) return rc;
   if ((rc = buf_in(c, bp, 1, points, n * terms * pin, mem))) return rc;
   if ((rc = buf_out(c, bo, 2, out, n * pout, mem))) return rc;
@@ -517,6 +480,29 @@ int ecgpu_msm(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* po
     HIPCHK(c, hipMemsetAsync(out, 0, pout, c->stream));
     if (out_fmt == ECGPU_PT_PROJECTIVE) HIPCHK(c, hipMemsetAsync(out + 2 * nb - 1, 1, 1, c->stream));
     return ECGPU_OK;
+  }
+  if (mem == ECGPU_MEM_HOST && n >= MSM_PIPE_MIN) {
+    // A large sum from host memory is cut into parts that stream through the pipeline's slots (round 3 staged the WHOLE input - 6.4 GB
+    // at 2^26 terms - before the first kernel started): part i is summed while part i + 1 uploads; every part leaves ONE projective
+    // point on the device and the parts are added up at the end (a sum with unit scalars: same output formatting as one call).
+    const std::vector<size_t> sizes = hostpipe::schedule(n, MSM_PIPE_PART / 2, MSM_PIPE_PART, 0, MSM_PIPE_PART / 8);
+    const size_t parts = sizes.size();
+    if ((rc = stage_reserve(c, 3, parts * 3 * nb))) return rc;
+    if ((rc = stage_reserve(c, 4, parts * nb))) return rc;
+    uint8_t* partial = (uint8_t*)c->stage[3];
+    const PipeArg args[2] = {{scalars, nullptr, nb}, {points, nullptr, pin}};
+    rc = hostpipe::run(c, args, 2, sizes, false, [&](int slot, size_t bytes) { return stage_reserve(c, slot, bytes); },
+                       [&](void** d, size_t cnt, size_t ci) {
+                         return ops->msm(c, (const uint32_t*)d[0], (const uint32_t*)d[1], pt_fmt, cnt, (uint32_t*)(partial + ci * 3 * nb), ECGPU_PT_PROJECTIVE);
+                       });
+    if (rc) return rc;
+    std::vector<uint8_t> ones(parts * nb, 0);
+    for (size_t i = 0; i < parts; i++) ones[i * nb + nb - 1] = 1;
+    HIPCHK(c, hipMemcpyAsync(c->stage[4], ones.data(), parts * nb, hipMemcpyHostToDevice, c->stream));
+    if ((rc = buf_out(c, bo, 2, out, pout, mem))) return rc;
+    if ((rc = ops->msm(c, (const uint32_t*)c->stage[4], (const uint32_t*)partial, ECGPU_PT_PROJECTIVE, parts, (uint32_t*)bo.dev, out_fmt))) return rc;
+    if ((rc = buf_finish(c, bo))) return rc;
+    return finish_host(c, mem);              // (`ones` lives until the stream has been synchronised here)
   }
   if ((rc = buf_in(c, bs, 0, scalars, n * nb, mem))) return rc;
   if ((rc = buf_in(c, bp, 1, points, n * pin, mem))) return rc;
@@ -632,9 +618,9 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* c, int curve, const uint8_t* prehash, co
   if (!c || !prehash || !sig_rs || !pubkeys_xy || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
   if (n == 0) return ECGPU_OK;
   ENTER(c, curve);
-  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
+  if (mem == ECGPU_MEM_HOST && n >= PIPE_MIN) {
     const PipeArg args[4] = {{prehash, nullptr, nb}, {sig_rs, nullptr, 2 * nb}, {pubkeys_xy, nullptr, 2 * nb}, {nullptr, ok, 1}};
-    return host_pipeline(c, args, 4, n, [&](void** d, size_t cnt) {
+    return host_pipeline(c, args, 4, n, ops->pass_units(c, 1, 1, 0), false, [&](void** d, size_t cnt) {
       return ops->ecdsa_verify(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (const uint32_t*)d[2], (uint8_t*)d[3], cnt, flags);
     });
   }
@@ -668,9 +654,9 @@ int ecgpu_ecdsa_recover_batch(ecgpu_ctx* c, int curve, const uint8_t* prehash, c
   if (!c || !prehash || !sig_rs || !recovery_id || !pubkeys_xy || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
   if (n == 0) return ECGPU_OK;
   ENTER(c, curve);
-  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
+  if (mem == ECGPU_MEM_HOST && n >= PIPE_MIN) {
     const PipeArg args[5] = {{prehash, nullptr, nb}, {sig_rs, nullptr, 2 * nb}, {recovery_id, nullptr, 1}, {nullptr, pubkeys_xy, 2 * nb}, {nullptr, ok, 1}};
-    return host_pipeline(c, args, 5, n, [&](void** d, size_t cnt) {
+    return host_pipeline(c, args, 5, n, ops->pass_units(c, 1, 1, 0), false, [&](void** d, size_t cnt) {
       return ops->ecdsa_recover(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (const uint8_t*)d[2], (uint32_t*)d[3], (uint8_t*)d[4], cnt, flags);
     });
   }
@@ -693,9 +679,9 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx* c, int curve, const uint8_t* pubkeys_x
   if (!c || !pubkeys_x || !sig_rs || !challenges || !ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
   if (n == 0) return ECGPU_OK;
   ENTER(c, curve);
-  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
+  if (mem == ECGPU_MEM_HOST && n >= PIPE_MIN) {
     const PipeArg args[4] = {{pubkeys_x, nullptr, nb}, {sig_rs, nullptr, 2 * nb}, {challenges, nullptr, nb}, {nullptr, ok, 1}};
-    return host_pipeline(c, args, 4, n, [&](void** d, size_t cnt) {
+    return host_pipeline(c, args, 4, n, ops->pass_units(c, 1, 1, 0), false, [&](void** d, size_t cnt) {
       return ops->schnorr_verify(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (const uint32_t*)d[2], (uint8_t*)d[3], cnt);
     });
   }
@@ -715,12 +701,12 @@ int ecgpu_ecdsa_sign_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, con
   if (n == 0) return ECGPU_OK;
   ENTER(c, curve);
   SecretWipe wipe(c);                        // staged secret keys and nonces are cleared on every exit path
-  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
-    for (int sl = 0; sl < 2; sl++)
-      for (int a = 0; a < 2; a++) wipe.arm(6 + sl * PIPE_MAXARGS + a, PIPE_CHUNK * nb);
+  if (mem == ECGPU_MEM_HOST && n >= PIPE_MIN) {
+    wipe.arm_pipeline(0); wipe.arm_pipeline(1);          // secret keys, nonces
     const PipeArg args[6] = {{secret_d, nullptr, nb}, {nonce_k, nullptr, nb}, {prehash, nullptr, nb}, {nullptr, sig_rs, 2 * nb},
                              {nullptr, recovery_id, 1}, {nullptr, ok, 1}};
-    int prc = host_pipeline(c, args, 6, n, [&](void** d, size_t cnt) {
+    const unsigned fb_flags = (flags & ECGPU_PUBLIC_SCALARS) ? 0u : (flags & ECGPU_EXACT_REFERENCE) ? (unsigned)ECGPU_EXACT_REFERENCE : (unsigned)ECGPU_SECRET_SCALARS;
+    int prc = host_pipeline(c, args, 6, n, ops->pass_units(c, 0, 1, fb_flags), true, [&](void** d, size_t cnt) {
       return ops->ecdsa_sign(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (const uint32_t*)d[2], (uint32_t*)d[3], (uint8_t*)d[4], (uint8_t*)d[5], cnt,
                              flags);
     });
@@ -749,16 +735,16 @@ int ecgpu_ecdh_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, const uin
   if (n == 0) return ECGPU_OK;
   ENTER(c, curve);
   SecretWipe wipe(c);                        // the staged secret scalars are cleared on every exit path
-  if (mem == ECGPU_MEM_HOST && n >= 2 * PIPE_CHUNK) {
-    for (int sl = 0; sl < 2; sl++) { wipe.arm(6 + sl * PIPE_MAXARGS, PIPE_CHUNK * nb); wipe.arm(6 + sl * PIPE_MAXARGS + 2, PIPE_CHUNK * nb); }   // secrets, shared values
+  if (mem == ECGPU_MEM_HOST && n >= PIPE_MIN) {
+    wipe.arm_pipeline(0); wipe.arm_pipeline(2);          // secrets, shared values
     const PipeArg args[4] = {{secret_d, nullptr, nb}, {pubkeys_xy, nullptr, 2 * nb}, {nullptr, shared_x, nb}, {nullptr, ok, 1}};
-    return host_pipeline(c, args, 4, n, [&](void** d, size_t cnt) {
+    return host_pipeline(c, args, 4, n, ops->pass_units(c, 1, 1, ECGPU_SECRET_SCALARS), true, [&](void** d, size_t cnt) {
       return ops->ecdh(c, (const uint32_t*)d[0], (const uint32_t*)d[1], (uint32_t*)d[2], (uint8_t*)d[3], cnt);
     });
   }
   Buf bd, bq, bs, bo;
   int rc;
-  if (mem == ECGPU_MEM_HOST) wipe.arm(0, n * nb);
+  if (mem == ECGPU_MEM_HOST) { wipe.arm(0, n * nb); wipe.arm(2, n * nb); }   // the staged secrets AND the staged shared values, whichever way the call ends
   if ((rc = buf_in(c, bd, 0, secret_d, n * nb, mem))) return rc;
   if ((rc = buf_in(c, bq, 1, pubkeys_xy, n * 2 * nb, mem))) return rc;
   if ((rc = buf_out(c, bs, 2, shared_x, n * nb, mem))) return rc;
@@ -766,7 +752,6 @@ int ecgpu_ecdh_batch(ecgpu_ctx* c, int curve, const uint8_t* secret_d, const uin
   if ((rc = ops->ecdh(c, (const uint32_t*)bd.dev, (const uint32_t*)bq.dev, (uint32_t*)bs.dev, (uint8_t*)bo.dev, n))) return rc;
   if ((rc = buf_finish(c, bs))) return rc;
   if ((rc = buf_finish(c, bo))) return rc;
-  if (mem == ECGPU_MEM_HOST) wipe.arm(2, n * nb);   // the staged copy of the shared secrets goes as well (after the download, ordered on the stream)
   return finish_host(c, mem);
 }
 

@@ -21,15 +21,22 @@ struct ecgpu_ctx {
   std::mutex mu;
   std::mutex err_mu;                          // guards err[] (ecgpu_set_err / ecgpu_last_error_copy)
   int64_t opt[ECGPU_OPT_COUNT_] = {0, 26, 0, 0, 1, 0, 4, 0};      // ecgpu_option defaults
-  // grow-only device staging buffers for ECGPU_MEM_HOST calls
-  static constexpr int NSTAGE = 18;          // 6 for whole-batch staging + 2 pipeline slots x 6 arguments
+  // grow-only device staging buffers for ECGPU_MEM_HOST calls: 6 for whole-batch staging, then PIPE_NSLOT pipeline slots x PIPE_MAXARGS arguments
+  static constexpr int PIPE_NSLOT = 3, PIPE_MAXARGS = 6, PIPE_STAGE0 = 6;
+  static constexpr int NSTAGE = PIPE_STAGE0 + PIPE_NSLOT * PIPE_MAXARGS;
   void* stage[NSTAGE] = {};
   size_t stage_cap[NSTAGE] = {};
-  // download and upload streams + events of the chunked host-buffer pipeline (ecgpu.hip: host_pipeline)
+  // chunked host-buffer pipeline (host_pipe.hpp): download and upload streams, per-slot events (inputs arrived / kernels done /
+  // outputs read), and the page-locked bounce buffers pageable caller memory is copied through ([0] uploads, [1] downloads)
+  static constexpr int PIPE_NWORK = 4;
+  static constexpr size_t PIPE_BOUNCE = (size_t)4 << 20;
   hipStream_t copy_stream = nullptr;
   hipStream_t up_stream = nullptr;
-  hipEvent_t ev_kernel[2] = {nullptr, nullptr};
-  hipEvent_t ev_up[2] = {nullptr, nullptr};
+  hipEvent_t ev_kernel[PIPE_NSLOT] = {};
+  hipEvent_t ev_up[PIPE_NSLOT] = {};
+  hipEvent_t ev_down[PIPE_NSLOT] = {};
+  void* bounce[2][PIPE_NWORK] = {};
+  hipEvent_t ev_bounce[2][PIPE_NWORK] = {};
   // precomputed generator tables, one per curve, built on first use
   void* gen_table[3] = {nullptr, nullptr, nullptr};
   // fixed-base tables of the throughput schedule (fixedbase.hpp)
@@ -102,6 +109,9 @@ struct ecgpu_curve_ops {
   int (*ecdsa_sign)(ecgpu_ctx* c, const uint32_t* d, const uint32_t* k, const uint32_t* z, uint32_t* sig, uint8_t* recid, uint8_t* ok,
                     size_t n, unsigned flags);
   int (*ecdh)(ecgpu_ctx* c, const uint32_t* d, const uint32_t* q_xy, uint32_t* shared_x, uint8_t* ok, size_t n);
+  // units of one whole pass of the kernel `lincomb` would pick: every resident lane gets its full sub-batch (the results that share
+  // one inversion).  The host-buffer pipeline sizes its chunks by it (host_pipe.hpp).
+  size_t (*pass_units)(const ecgpu_ctx* c, int has_points, size_t terms, unsigned flags);
 };
 // Pippenger MSM, one translation unit per curve (msm_*.hip); `mul` is the curve's batch scalar multiplication (affine in / out
 // on device memory), used for small sums

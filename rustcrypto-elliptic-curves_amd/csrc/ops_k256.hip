@@ -67,6 +67,14 @@ int CurveOps<CurveK256>::mul_ct(ecgpu_ctx* c, const u32* sc, const u32* pts, int
   HIPCHK(c, hipGetLastError());
   return 1;
 }
+template <>
+size_t CurveOps<CurveK256>::pass_units_points(const ecgpu_ctx* c, size_t terms, unsigned flags) {
+  if (flags & ECGPU_EXACT_REFERENCE) return resident_lanes(c, 4);                          // lincomb_ref_kernel: one unit per lane
+  if (flags & ECGPU_SECRET_SCALARS) return resident_lanes(c, K256_CT_WAVES) * K256_CT_BATCH;
+  if (terms == 2) return resident_lanes(c, 4) * 16;
+  if (terms > 2) return resident_lanes(c, 4);
+  return resident_lanes(c, c->opt[ECGPU_OPT_K256_WAVES] == 3 ? 3 : 4) * K256_FAST_BATCH;
+}
 // Pippenger MSM (msm.hpp, msm_kernels.hpp; instantiated in msm_k256.hip)
 static int k256_mul_for_msm(ecgpu_ctx* c, const u32* s, const u32* p, int fmt, u32* prod, size_t cnt) {
   return CurveOps<CurveK256>::lincomb(c, s, p, fmt, 1, prod, FMT_AFFINE, nullptr, cnt, 0);

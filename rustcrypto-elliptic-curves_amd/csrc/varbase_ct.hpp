@@ -310,6 +310,10 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
     fe_mask_select<C>(acc.z, inf, one, acc.z);          // keep the shared inversion clean
     jac_st<C>(ws, entry_chunk<C>(b, 0), acc);
   }
+#ifndef ECGPU_DIGITS_IN_REGISTERS
+#pragma unroll
+  for (int w = 0; w < NW; w++) dm.st(w, 0u);            // the last unit's recoded scalar does not stay in LDS
+#endif
   // ---- phase D: x = X / Z^2, y = Y / Z^3 with one inversion for the cnt results of this lane
   {
     Fe run = one;
@@ -318,6 +322,11 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
       Fe z;
       fe_st<C>(ws, pre_chunk<C, BATCH>(b), run);
       fe_ld<C>(z, ws, entry_chunk<C>(b, 0) + 2 * CW);
+      // Z = 0 besides the tracked identities: only for input that is not on the curve (a small-order point of another cubic makes the raw
+      // addition meet acc = +-Q).  It must not reach the shared product: fe_inv(0) = 0 would wipe every result of this lane's pass.
+      const u32 zm = fe_zero_mask<C>(z) | (0u - ((res_inf >> b) & 1u));
+      res_inf |= (zm & 1u) << b;
+      fe_mask_select<C>(z, zm, one, z);
       C::fe_mul(run, run, z);
     }
     Fe inv;
@@ -328,6 +337,7 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
       const u32 inf = 0u - ((res_inf >> b) & 1u);
       Fe z, pre, zi, t, x, yv;
       fe_ld<C>(z, ws, entry_chunk<C>(b, 0) + 2 * CW);
+      fe_mask_select<C>(z, inf, one, z);
       fe_ld<C>(pre, ws, pre_chunk<C, BATCH>(b));
       C::fe_mul(zi, inv, pre);
       C::fe_mul(inv, inv, z);
@@ -337,6 +347,9 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
       C::fe_mul(t, t, zi);
       fe_ld<C>(yv, ws, entry_chunk<C>(b, 0) + CW);
       C::fe_mul(yv, yv, t);
+      // the parked result and its prefix product are secrets of the same rank as the output: they do not stay in the workspace
+      fe_st<C>(ws, entry_chunk<C>(b, 0), zero); fe_st<C>(ws, entry_chunk<C>(b, 0) + CW, zero); fe_st<C>(ws, entry_chunk<C>(b, 0) + 2 * CW, zero);
+      fe_st<C>(ws, pre_chunk<C, BATCH>(b), zero);
       fe_mask_select<C>(x, inf, zero, x);
       if (out_fmt == FMT_PROJECTIVE) {          // public: the wire format.  (x : y : 1), identity (0 : 1 : 0)
         Fe zo;

@@ -243,6 +243,8 @@ ECGPU_HD void lane_pass_k256(const u32* scalars, const u32* points, int pt_fmt, 
     res_inf |= (inf & 1u) << b;
     fe_st<C>(ws, k256_res_chunk<BATCH>(b), acc.x); fe_st<C>(ws, k256_res_chunk<BATCH>(b) + CW, acc.y); fe_st<C>(ws, k256_res_chunk<BATCH>(b) + 2 * CW, acc.z);
   }
+#pragma unroll
+  for (int w = 0; w < 8; w++) dm.st(w, 0u);             // the last unit's recoded halves do not stay in LDS
   // ---- x = X / Z^2, y = Y / Z^3 with one inversion for the cnt results of this lane
   {
     FeK256 run = one;
@@ -274,6 +276,9 @@ ECGPU_HD void lane_pass_k256(const u32* scalars, const u32* points, int pt_fmt, 
       k256::mul(x, x, zi2);
       fe_ld<C>(yv, ws, k256_res_chunk<BATCH>(b) + CW);
       k256::mul(yv, yv, zi3);
+      // the parked result and its prefix product are secrets of the same rank as the output: they do not stay in the workspace
+      fe_st<C>(ws, k256_res_chunk<BATCH>(b), zero); fe_st<C>(ws, k256_res_chunk<BATCH>(b) + CW, zero); fe_st<C>(ws, k256_res_chunk<BATCH>(b) + 2 * CW, zero);
+      fe_st<C>(ws, k256_pre_chunk<BATCH>(b), zero);
       k256_mask_select(x, inf, zero, x);
       if (out_fmt == FMT_PROJECTIVE) {          // public: the wire format.  (x : y : 1), identity (0 : 1 : 0)
         FeK256 zo;

@@ -41,6 +41,15 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("ECGPU_LIB") or os.path.join(_PKG_ROOT, "lib", "libecgpu.so")
 
 
+def host_chunk_schedule(n: int, pass_units: int) -> list:
+    """chunk sizes of a host-buffer batch (ecgpu_host_chunk_schedule; no device needed)"""
+    lib = load_library()
+    cnt = lib.ecgpu_host_chunk_schedule(n, pass_units, None, 0)
+    arr = (ctypes.c_size_t * max(cnt, 1))()
+    lib.ecgpu_host_chunk_schedule(n, pass_units, arr, cnt)
+    return list(arr[:cnt])
+
+
 class EcgpuError(RuntimeError):
     pass
 
@@ -78,6 +87,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.ecgpu_field_bytes.restype = sz
     lib.ecgpu_host_alloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
     lib.ecgpu_host_free.argtypes = [vp, vp]
+    lib.ecgpu_debug_workspace.argtypes = [vp, i, vp, sz, ctypes.POINTER(sz)]
+    lib.ecgpu_host_chunk_schedule.argtypes = [sz, sz, ctypes.POINTER(sz), sz]
     lib.ecgpu_timer_start.argtypes = [vp]
     lib.ecgpu_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.ecgpu_field_op_batch.argtypes = [vp, i, i, u8p, u8p, u8p, sz, i]
@@ -112,7 +123,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
                  "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch",
                  "ecgpu_ecdsa_recover_batch", "ecgpu_map_to_curve_batch", "ecgpu_use_own_stream", "ecgpu_last_error_copy",
                  "ecgpu_set_option", "ecgpu_get_option", "ecgpu_fb_table_bytes", "ecgpu_sec1_encode_batch", "ecgpu_sec1_decode_batch",
-                 "ecgpu_ecdh_batch"):
+                 "ecgpu_ecdh_batch", "ecgpu_debug_workspace", "ecgpu_host_chunk_schedule"):
         getattr(lib, name).restype = ctypes.c_int
     if path is None:
         _lib = lib
@@ -128,7 +139,7 @@ EXPORTED_SYMBOLS = (
     "ecgpu_to_bytes_batch", "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch", "ecgpu_ecdsa_recover_batch", "ecgpu_map_to_curve_batch",
     "ecgpu_point_eq_batch", "ecgpu_mul_batch_checked", "ecgpu_lincomb_batch_checked",
     "ecgpu_use_own_stream", "ecgpu_last_error_copy", "ecgpu_set_option", "ecgpu_get_option", "ecgpu_fb_table_bytes",
-    "ecgpu_sec1_encode_batch", "ecgpu_sec1_decode_batch", "ecgpu_ecdh_batch",
+    "ecgpu_sec1_encode_batch", "ecgpu_sec1_decode_batch", "ecgpu_ecdh_batch", "ecgpu_debug_workspace", "ecgpu_host_chunk_schedule",
 )
 
 
@@ -206,6 +217,17 @@ class Context:
         buf = ctypes.create_string_buffer(512)
         self.lib.ecgpu_last_error_copy(self.handle, buf, 512)
         return buf.value.decode()
+
+    def debug_workspace(self, which: int) -> bytes:
+        """contents of one of the context's device workspaces (ecgpu_debug_workspace): 0 table workspace, 1 ECDSA / ECDH
+        intermediates, 2 MSM, 16 + i staging slot i.  b"" if it does not exist yet."""
+        b = ctypes.c_size_t()
+        self.check(self.lib.ecgpu_debug_workspace(self.handle, which, None, 0, ctypes.byref(b)))
+        if not b.value:
+            return b""
+        buf = np.empty(b.value, dtype=np.uint8)
+        self.check(self.lib.ecgpu_debug_workspace(self.handle, which, ctypes.c_void_p(buf.ctypes.data), b.value, ctypes.byref(b)))
+        return buf.tobytes()
 
     def synchronize(self):
         self.check(self.lib.ecgpu_synchronize(self.handle))

@@ -68,6 +68,8 @@ extern "C" {
     pub fn ecgpu_field_bytes(curve: c_int) -> usize;
     pub fn ecgpu_host_alloc(ctx: *mut ecgpu_ctx, bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn ecgpu_host_free(ctx: *mut ecgpu_ctx, p: *mut c_void) -> c_int;
+    pub fn ecgpu_host_chunk_schedule(n: usize, pass_units: usize, sizes: *mut usize, cap: usize) -> c_int;
+    pub fn ecgpu_debug_workspace(ctx: *mut ecgpu_ctx, which: c_int, host_copy: *mut c_void, cap: usize, bytes: *mut usize) -> c_int;
     pub fn ecgpu_timer_start(ctx: *mut ecgpu_ctx) -> c_int;
     pub fn ecgpu_timer_stop(ctx: *mut ecgpu_ctx, milliseconds: *mut f32) -> c_int;
     pub fn ecgpu_field_op_batch(ctx: *mut ecgpu_ctx, curve: c_int, op: c_int, a: *const u8, b: *const u8, out: *mut u8, n: usize, mem: c_int) -> c_int;

@@ -84,3 +84,27 @@ def test_c_caller_links_and_fails_loudly_without_gpu():
         pytest.skip("a GPU is present (test_gpu_api.py runs the example)")
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "no usable gfx950 device" in r.stderr
+
+
+def test_host_chunk_schedule():
+    """The chunking of host-buffer batches (csrc/host_pipe.hpp) is host logic and needs no device: sizes add up, grow from an eighth
+    of a pass to a whole pass, end small (short drain), and leave no crumbs."""
+    if not os.path.exists(ecgpu.LIB_PATH):
+        pytest.skip("libecgpu.so not built")
+    P = 1 << 23
+    assert ecgpu.host_chunk_schedule(1 << 24, P) == [1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 20]
+    assert ecgpu.host_chunk_schedule(1 << 25, P) == [1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 23, 1 << 23, 1 << 20]
+    assert ecgpu.host_chunk_schedule((1 << 21) + 12345, P) == [1 << 20, (1 << 20) + 12345]
+    assert ecgpu.host_chunk_schedule((1 << 22) + (1 << 20) + 4321, P) == [1 << 20, 1 << 21, (1 << 20) + 4321, 1 << 20]
+    import random
+    rng = random.Random(5)
+    for _ in range(300):
+        n = rng.randrange(1, 1 << 27)
+        pass_units = 1 << rng.randrange(18, 26)
+        p = min(max(pass_units, 1 << 20), 1 << 23)
+        s = ecgpu.host_chunk_schedule(n, pass_units)
+        assert sum(s) == n and all(x > 0 for x in s)
+        assert all(x <= p + p // 16 for x in s), (n, pass_units, s)              # a chunk is at most a pass (plus an absorbed crumb)
+        if len(s) > 1:
+            assert s[-1] <= max(p // 8, 0) + p // 16 or s[-1] < 2 * (p // 8), (n, pass_units, s)   # short drain
+            assert all(x >= p // 16 for x in s), (n, pass_units, s)             # no crumbs

@@ -192,3 +192,106 @@ def test_ecdh_batch_entry_point(cname, cid):
         w = CO.lincomb_batch(cid, dm[idx], qm[idx], threads=THREADS)
         assert bytes(sh[idx]) == bytes(w[:, :nb])
     ctx.close()
+
+
+def _small_order_offcurve_points(c, orders=(5, 17)):
+    """points of small order on the singular cubic y^2 = x^3 - 3x - 2 (see tests/test_hosttwin_vbct.py)"""
+    import random
+    M = synth.M
+    p = c.p
+    N = p - 1 if pow((-3) % p, (p - 1) // 2, p) == 1 else p + 1
+    rng = random.Random(20260405)
+    out = []
+    for q in orders:
+        while True:
+            x = rng.randrange(p)
+            t = (x - 2) % p
+            if pow(t, (p - 1) // 2, p) != 1:
+                continue
+            P = M.affine_mul(c, N // q, (x, (x + 1) * M.field_sqrt(c, t) % p))
+            if P is not None:
+                out.append(P)
+                break
+    return out
+
+
+@pytest.mark.parametrize("cname,cid", [("p256", 1), ("p384", 2), ("k256", 0)])
+def test_invalid_public_key_does_not_poison_its_neighbours(cname, cid):
+    """a public key that is not on the curve - here points of order 5 and 17 on the singular cubic
+    y^2 = x^3 - 3x - 2, which walk the raw mixed addition into acc = +-Q so that Z = 0 - used to zero the VALID results that
+    shared its lane's output inversion, while those still reported ok = 1.  2^20 + 999 units: every lane holds several units.
+    (a) ecgpu_ecdh_batch: the bad keys get ok = 0 and zeros, every other unit is the oracle's; (b) ecgpu_mul_batch with
+    ECGPU_SECRET_SCALARS, which does not validate: the bad units' output is unspecified, every other unit is untouched."""
+    import torch
+    import ecgpu
+    c = synth.M.CURVES[cname]
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cname)
+    nb = cv.nb
+    n = (1 << 20) + 999
+    d = CO.synth_scalars(cid, n, synth.SEED, 21_000)
+    q = CO.synth_points(cid, n, synth.SEED, 21_000)
+    bad_pts = _small_order_offcurve_points(c) if cid else [(4, 8), (9, 27)]       # secp256k1: points of y^2 = x^3
+    lanes = 4 * torch.cuda.get_device_properties(0).multi_processor_count * 256
+    bad_idx = [7, lanes + 7, 2 * lanes + 70001, n - 2, 123456, 123457]
+    for j, i in enumerate(bad_idx):
+        P = bad_pts[j % len(bad_pts)]
+        q[i] = np.frombuffer(synth.M.i2b(c, P[0]) + synth.M.i2b(c, P[1]), dtype=np.uint8)
+    d_d, d_q = torch.from_numpy(d).cuda(), torch.from_numpy(q).cuda()
+    d_s = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
+    d_ok = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    cv.ecdh_device(d_d, d_q, d_s, d_ok, n)
+    d_o = torch.empty((n, 2 * nb), dtype=torch.uint8, device="cuda")
+    d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    cv.mul_device(d_d, d_q, d_o, n, d_out_inf=d_i, flags=ecgpu.SECRET_SCALARS)
+    # the public-data schedule on the valid units only is the reference for ALL of them (itself checked against the oracle below)
+    q_ok = q.copy()
+    for i in bad_idx:
+        q_ok[i] = q[0]
+    d_o2 = torch.empty_like(d_o)
+    cv.mul_device(d_d, torch.from_numpy(q_ok).cuda(), d_o2, n)
+    ctx.synchronize()
+    shared, ok, prod, ref = d_s.cpu().numpy(), d_ok.cpu().numpy(), d_o.cpu().numpy(), d_o2.cpu().numpy()
+    keep = np.ones(n, dtype=bool)
+    keep[bad_idx] = False
+    assert not ok[bad_idx].any() and ok[keep].all() and not shared[bad_idx].any()
+    assert (shared[keep] == ref[keep][:, :nb]).all(), "a valid unit's shared secret changed"
+    assert (prod[keep] == ref[keep]).all() and not d_i.cpu().numpy()[keep].any(), "a valid unit's product changed"
+    near = np.unique(np.clip(np.concatenate([np.array(bad_idx) + k * lanes for k in range(-3, 4)] + [np.arange(0, n, n // 512)]), 0, n - 1))
+    near = near[keep[near]]
+    want = CO.lincomb_batch(cid, d[near], q[near], threads=THREADS)
+    assert bytes(ref[near]) == bytes(want[:, :2 * nb])
+    ctx.close()
+
+
+@pytest.mark.parametrize("cname,cid", [("p256", 1), ("p384", 2), ("k256", 0)])
+def test_no_secret_stays_in_the_workspaces(cname, cid):
+    """include/ecgpu.h promises that the intermediate products of ecgpu_ecdh_batch do not stay in the context's
+    workspace.  The constant-time kernels park each result's Jacobian (X, Y, Z) and the prefix products of the output inversion in the
+    table workspace: they clear them themselves now.  After a call, neither the table workspace nor the ECDH workspace nor the
+    staging slots may hold a shared x, a secret scalar, or anything but public table data: checked by searching the workspaces for
+    the 32 / 48-byte strings (wire form and limb-reversed internal form) and by the parked-result regions being all zero."""
+    import torch
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cname)
+    nb = cv.nb
+    n = 70_000
+    d = CO.synth_scalars(cid, n, synth.SEED, 31_000)
+    q = CO.synth_points(cid, n, synth.SEED, 31_000)
+    shared, ok = cv.ecdh(d, q)                    # host buffers: staging slots 0 (secrets) and 2 (shared values) are used
+    assert ok.all()
+
+    dump = ctx.debug_workspace
+
+    tab, ws, st0, st2 = dump(0), dump(1), dump(16 + 0), dump(16 + 2)
+    assert len(tab) > 0 and len(ws) >= n * 4 * nb
+    assert not any(st0) and not any(st2), "staged secrets / shared values were left behind"
+    assert not any(ws[:n * 2 * nb]), "the products (shared points) were left in the ECDH workspace"
+    words = lambda b: b"".join(b[i:i + 4][::-1] for i in range(len(b) - 4, -1, -4))      # big-endian bytes -> little-endian 32-bit limbs, least significant first
+    for i in (0, 1, 63, 64, 255, 256, 4097, n - 1):
+        sx, dk = bytes(shared[i]), bytes(d[i])
+        for name, blob in (("table workspace", tab), ("ECDH workspace", ws)):
+            assert sx not in blob and words(sx) not in blob, (name, i, "shared x")
+            assert dk not in blob and words(dk) not in blob, (name, i, "secret scalar")
+    ctx.close()

@@ -93,9 +93,9 @@ def test_slice_against_c_oracle(env):
 
 
 def test_host_buffer_pipeline_matches_device_path(env):
-    """Host-buffer calls above 2^21 units stream through two device slots in 2^20-unit chunks (upload, kernels and
-    download overlapped, ecgpu.hip host_pipeline): results must be those of the one-shot device-resident call,
-    including the ragged last chunk."""
+    """Host-buffer calls of 2^21 units and more stream through three device slots in chunks that grow from an eighth of a kernel
+    pass to a whole pass (upload, kernels and download overlapped, csrc/host_pipe.hpp): results must be those of the one-shot
+    device-resident call, including the ragged last chunk.  Here: pageable numpy arrays (the bounce-buffer path), two chunks."""
     import torch
     ctx, cv = env
     n = (1 << 21) + 12345
@@ -174,3 +174,75 @@ def test_ragged_batch_sizes_are_prefix_consistent(cn, cid):
         assert bytes(cv.to_bytes(out[:n])) == bytes(enc[:n]), n
     assert ver.sum() == big - len(range(0, big, 7))
     ctx.close()
+
+
+def test_host_buffer_pipeline_slot_reuse_pinned_and_pageable(env):
+    """2^22 + 2^20 + 4321 units = four chunks (2^20, 2^21, 2^20 + 4321, 2^20: the fourth reuses the first slot) from page-locked
+    buffers (direct DMA) and from pageable ones (bounce pool, helper threads): byte-identical to the device-resident call, with the
+    per-element scalar verdicts of the checked entry point riding along as a fifth argument."""
+    import torch
+    import ecgpu
+    ctx, cv = env
+    n = (1 << 22) + (1 << 20) + 4321
+    assert ecgpu.host_chunk_schedule(n, 1 << 23) == [1 << 20, 1 << 21, (1 << 20) + 4321, 1 << 20]
+    d_s = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    d_p = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    d_o = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    d_i = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_s, n, synth.SEED, 424242)
+    cv.synth_points_device(d_p, n, synth.SEED, 424242)
+    edges = [0, (1 << 20) - 1, 1 << 20, (3 << 20) - 1, 3 << 20, (4 << 20) + 4320, (4 << 20) + 4321, n - 1]      # first / last unit of every chunk
+    for j, i in enumerate(edges):
+        if j % 2:
+            d_s[i] = 0                              # identity results at chunk boundaries
+        else:
+            d_s[i] = 255                            # 2^256 - 1 >= n: scalar_ok = 0, the result is that of the reduced scalar
+    cv.mul_device(d_s, d_p, d_o, n, d_out_inf=d_i)
+    ctx.synchronize()
+    want_o, want_i = d_o.cpu().numpy(), d_i.cpu().numpy()
+    hs, hp = d_s.cpu().numpy(), d_p.cpu().numpy()
+    out, inf, ok = cv.lincomb(hs, hp, checked=True)                  # pageable in, pageable out
+    assert bytes(out) == bytes(want_o) and bytes(inf) == bytes(want_i)
+    want_ok = np.ones(n, dtype=np.uint8)
+    want_ok[edges[0::2]] = 0
+    assert (ok == want_ok).all() and inf.sum() == len(edges) // 2
+    ps, pp = ctx.pinned_array((n, 32)), ctx.pinned_array((n, 64))
+    po, pi = ctx.pinned_array((n, 64)), ctx.pinned_array((n,))
+    ps[:] = hs
+    pp[:] = hp
+    po[:] = 0xA5
+    cv.mul(ps, pp, out=po, out_inf=pi)                                # page-locked in and out
+    assert bytes(po) == bytes(want_o) and bytes(pi) == bytes(want_i)
+    out2, inf2 = cv.mul(ps, hp)                                       # mixed: page-locked scalars, pageable points and outputs
+    assert bytes(out2) == bytes(want_o) and bytes(inf2) == bytes(want_i)
+
+
+def test_msm_from_host_memory_streams_in_parts(env):
+    """ecgpu_msm with host buffers cuts sums of 2^22 terms and more into parts that upload while the previous part is summed
+    (ecgpu.hip; round 3 staged the whole input first): 2^23 + 2^22 + 777 terms = three parts, equal to the device-resident sum
+    and to the closed form over structured scalars; affine and projective output."""
+    import torch
+    import ecgpu
+    ctx, cv = env
+    n = (1 << 23) + (1 << 22) + 777
+    d_s = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    d_p = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_s, n, synth.SEED, 606060)
+    cv.synth_points_device(d_p, n, synth.SEED, 606060)
+    d_s[12345] = 0
+    d_p[(1 << 22) + 5] = 0                       # an identity point in the second part
+    d_r = torch.empty((96,), dtype=torch.uint8, device="cuda")
+    cv.msm_device(d_s, d_p, n, d_r[:64])
+    ctx.synchronize()
+    want = bytes(d_r[:64].cpu().numpy())
+    hs, hp = d_s.cpu().numpy(), d_p.cpu().numpy()
+    assert bytes(cv.msm(hs, hp)) == want                                              # pageable
+    proj = bytes(cv.msm(hs, hp, out_format=ecgpu.PROJECTIVE))
+    assert proj[:64] == want and proj[64:] == (1).to_bytes(32, "big")
+    ps, pp = ctx.pinned_array((n, 32)), ctx.pinned_array((n, 64))
+    ps[:] = hs
+    pp[:] = hp
+    assert bytes(cv.msm(ps, pp)) == want                                              # page-locked
+    # all-identity parts: the sum of the first 2^22 + 5 terms with zero scalars is the identity, whatever the parts hold
+    zs = np.zeros((1 << 22) + 5, dtype=np.uint8).reshape(-1, 1).repeat(32, axis=1)
+    assert bytes(cv.msm(zs, hp[:len(zs)])) == bytes(64)

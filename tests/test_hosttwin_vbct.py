@@ -177,3 +177,50 @@ def test_vbct_reads_the_whole_table_for_every_scalar(cn, cid):
     nwin = 33 if cid == 0 else 2 * nb + 1               # k256: 32 nibbles of a GLV half and the carry digits (one scan serves both halves); else 8 NW nibbles and the carry digit
     assert all(t == traces[0] for t in traces)
     assert traces[0] == list(range(8)) * nwin
+
+
+def small_order_offcurve_points(c, orders=(5, 17)):
+    """Points of small order on the singular cubic y^2 = x^3 - 3x - 2 = (x + 1)^2 (x - 2): not on the curve, yet the a = -3
+    formulas (which never use b) act on them as a group of order p - 1 or p + 1.  A windowed schedule walks such a point into
+    acc = +-Q within a few digits, so the raw mixed addition leaves Z = 0 (one such key in an ECDH batch used
+    to zero the valid neighbours that shared its lane's output inversion)."""
+    p = c.p
+    N = p - 1 if pow((-3) % p, (p - 1) // 2, p) == 1 else p + 1
+    rng = random.Random(20260405)
+    out = []
+    for q in orders:
+        assert N % q == 0
+        while True:
+            x = rng.randrange(p)
+            t = (x - 2) % p
+            if pow(t, (p - 1) // 2, p) != 1:
+                continue
+            P = M.affine_mul(c, N // q, (x, (x + 1) * M.field_sqrt(c, t) % p))
+            if P is not None:
+                assert M.affine_mul(c, q, P) is None and not M.on_curve(c, P)
+                out.append(P)
+                break
+    return out
+
+
+@pytest.mark.parametrize("cn,cid", CURVES)
+@pytest.mark.parametrize("fn", ["ht_vbct_mul16", "ht_vbct_mul"])
+def test_offcurve_small_order_point_does_not_poison_its_lane(cn, cid, fn):
+    """One lane, so every unit of the pass shares ONE output inversion with the invalid points: each valid neighbour must come back
+    bit-exact.  (secp256k1 has a = 0: its singular companion is y^2 = x^3; the same planted inputs exercise its Z guard.)"""
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    if cid == 0:
+        bad = [(4, 8), (9, 27)]                    # on y^2 = x^3 (additive group: every point has order p); plus x = 0 cases below
+    else:
+        bad = small_order_offcurve_points(c)
+    n = 8
+    ks = [synth.scalar(c, 9100 + i) for i in range(n)]
+    ps = [synth.point(c, 9100 + i) for i in range(n)]
+    ps[2], ps[5] = bad[0], bad[1]
+    out, inf = _vbct(cid, c, ks, ps, 1, fn=fn)
+    for i in range(n):
+        if i in (2, 5):
+            continue                               # unspecified output for input that violates the reference's type invariant
+        want = M.affine_mul(c, ks[i] % c.n, ps[i])
+        assert out[2 * nb * i:2 * nb * (i + 1)] == M.i2b(c, want[0]) + M.i2b(c, want[1]) and inf[i] == 0, i
