@@ -28,6 +28,9 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
                 available) timed on this box's host cores on a bounded sample of the same workload
                 (median of 5, all cores and single thread), and used to check the GPU output of that
                 sample byte for byte.
+  host_io       (N = 1, variable-base workloads) the same batch handed over in HOST memory - what a drop-in caller of the reference's
+                trait surface does - through the chunked pipeline of csrc/host_pipe.hpp: PCIe-inclusive rate from page-locked and from
+                pageable buffers, each compared byte for byte with the device-resident result.  Never `value`.
   other_configs (N = 1, default workload only) the other BASELINE.json configs - p256 fixed base 2^24,
                 k256 MSM 2^23 terms, p384 variable base 2^22 - run for a few steps each after the
                 headline, with their own parity checks, so that every config has a driver-run number.
@@ -507,10 +510,51 @@ def run_workload(env, name, log2n, steps, warmup, schedule, cpu):
         t = torch.tensor([1 if parity else 0], dtype=torch.int32, device=(dev if backend == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         parity = bool(t.item())
+    host_io = None
+    if env.get("host_io") and not wl["msm"] and not wl.get("ecdsa") and not wl["fixed"] and schedule == "fast":
+        host_io = measure_host_io(env, cv, d_s, d_p, d_o, d_i, n, wl)
+        parity &= host_io["pinned"]["parity_ok"] and host_io["pageable"]["parity_ok"]
     del d_s, d_p, d_o, d_i
     torch.cuda.empty_cache()
     return {"name": name, "n": n, "log2n": log2n, "elapsed": elapsed, "kernel_ms": kernel_ms / steps, "steps": steps, "parity": bool(parity), "checked": checked,
-            "value": world * n * steps / elapsed, "table": table}
+            "value": world * n * steps / elapsed, "table": table, "host_io": host_io}
+
+
+def measure_host_io(env, cv, d_s, d_p, d_o, d_i, n, wl, reps=3):
+    """The same batch through the C ABI with HOST buffers (ECGPU_MEM_HOST: what a caller on the reference's side of the boundary hands
+    over, k256/src/arithmetic/mul.rs:442-481 - values in host memory): upload, kernels and download, end to end, wall clock around
+    the blocking call.  Page-locked buffers (ecgpu_host_alloc) and ordinary pageable numpy arrays (already touched: a caller's
+    buffers are not fresh from calloc); outputs compared byte for byte with the device-resident result d_o / d_i.
+    Never `value`: that is the device-resident rate."""
+    import numpy as np
+    ctx = env["ctx"]
+    nb = cv.nb
+    ctx.synchronize()
+    want_o, want_i = d_o.cpu().numpy().tobytes(), d_i.cpu().numpy().tobytes()
+    hs, hp = d_s.cpu().numpy(), d_p.cpu().numpy()
+    unit_bytes = wl["bytes_per_unit"]
+    res = {"units": n, "bytes_per_unit_over_pcie": unit_bytes, "chunks": env["ecgpu"].host_chunk_schedule(n, (1 << 23) if wl["curve"] == "k256" else (1 << 22)),     # one pass: 32 (k256) / 16 results per resident lane
+           "note": "PCIe-inclusive: wall clock of one blocking ecgpu_mul_batch call with ECGPU_MEM_HOST; best and median of %d calls; never `value`" % reps}
+    out, inf = np.ones((n, 2 * nb), dtype=np.uint8), np.ones(n, dtype=np.uint8)
+    bufs = {"pageable": (hs, hp, out, inf)}
+    ps, pp = ctx.pinned_array((n, nb)), ctx.pinned_array((n, 2 * nb))
+    po, pi = ctx.pinned_array((n, 2 * nb)), ctx.pinned_array((n,))
+    ps[:] = hs
+    pp[:] = hp
+    bufs["pinned"] = (ps, pp, po, pi)
+    for kind in ("pinned", "pageable"):
+        a, b, o, i = bufs[kind]
+        times = []
+        for _ in range(reps):
+            o[:1] = 0xA5
+            t0 = time.perf_counter()
+            cv.mul(a, b, out=o, out_inf=i)
+            times.append(time.perf_counter() - t0)
+        ok = (o.tobytes() == want_o) and (i.tobytes() == want_i)
+        best, med = min(times), median(times)
+        res[kind] = {"rate": n / med, "rate_best": n / best, "unit": wl["unit"], "ms": med * 1e3, "ms_best": best * 1e3,
+                     "pcie_gb_per_s": n * unit_bytes / med / 1e9, "parity_ok": bool(ok)}
+    return res
 
 
 def roofline_for(name, res, schedule, peak_meas, pair_meas, world=1):
@@ -544,6 +588,12 @@ def roofline_for(name, res, schedule, peak_meas, pair_meas, world=1):
                    "kernel_match": pmc.get("kernel_match"), "profiled_kernel_ms": (kt.get("avg_ns") / 1e6 if kt.get("avg_ns") else None),
                    "hbm_bytes_per_launch": pmc.get("hbm_bytes_per_launch"), "traffic_over_algorithmic": (pmc["hbm_bytes_per_launch"] / (n * wl["bytes_per_unit"])
                                                                                                       if pmc.get("hbm_bytes_per_launch") else None),
+                   # the same counters under the guide's rule for wide streaming reads (FETCH_SIZE x 2): the upper reading.  hbm_bytes_per_launch
+                   # follows the calibration on this kernel's known read volume (fetch_calibration: "raw" for lane-divergent 64-byte blocks)
+                   "hbm_bytes_per_launch_x2_streaming_rule": pmc.get("hbm_bytes_per_launch_x2_streaming_rule"),
+                   "traffic_over_algorithmic_x2_streaming_rule": (pmc["hbm_bytes_per_launch_x2_streaming_rule"] / (n * wl["bytes_per_unit"])
+                                                                  if pmc.get("hbm_bytes_per_launch_x2_streaming_rule") else None),
+                   "fetch_calibration": pmc.get("fetch_calibration"),
                    "l2_hit_rate": pmc.get("l2_hit_rate"), "valu_insts_per_launch": ctr.get("SQ_INSTS_VALU"),
                    "valu_issue_slots_pct": issue_slots, "valu_cycles_per_inst": valu_cpi, "issue_stall_frac": stall,
                    # the clock the chip held inside the profiled kernel (GRBM_GUI_ACTIVE / 8 XCDs / the dispatch's own duration): the kernels
@@ -585,6 +635,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="processes of the all-core CPU baseline (0 = all host cores, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs 3, 4, 5 after the headline")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the host-buffer (PCIe-inclusive) runs of the variable-base workloads at N = 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse several ranks on one GPU)")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: initialise a world-size-1 process group all the same, so that the split-MSM step runs its collective branch "
@@ -655,7 +706,7 @@ def main():
     stream = torch.cuda.Stream(device=local_rank)
     ctx.set_stream(stream.cuda_stream)
     env = {"torch": torch, "ecgpu": ecgpu, "ctx": ctx, "dev": torch.device("cuda", local_rank), "rank": rank, "world": world, "dist": dist,
-           "backend": args.backend}
+           "backend": args.backend, "host_io": (world == 1 and rank == 0 and not args.no_host_io and args.log2n >= 21)}
 
     with torch.cuda.stream(stream):
         res = run_workload(env, args.workload, args.log2n, args.steps, args.warmup, args.schedule, cpu)
@@ -694,9 +745,11 @@ def main():
         }
         if res.get("table"):
             line["generator_table"] = res["table"]
+        if res.get("host_io"):
+            line["host_io"] = res["host_io"]
         if cpu is not None:
             line["cpu_baseline"] = {
-                "value": cpu["rate"], "unit": wl["unit"], "cores": cpu["procs"], "kind": "port",
+                "value": cpu["rate"], "unit": wl["unit"], "cores": cpu["procs"], "host_nproc": os.cpu_count(), "kind": "port",
                 "sample": "first %d units of the same seeded batch, C restatement of the reference path (oracle/ecoracle.c), %d single-threaded processes, each slice timed in %d chunks: median chunk rate" % (
                     cpu["sample"], cpu["procs"], cpu["reps"]),
                 "single_thread": {"value": cpu["single_rate"], "cores": 1, "median_of": cpu["reps"]},
@@ -711,12 +764,14 @@ def main():
                        "roofline": roofline_for(r["name"], r, "fast", peak_meas, pair_meas)}
                 c2 = cpu_others.get(r["name"])
                 if c2 is not None:
-                    ent["cpu_baseline"] = {"value": c2["rate"], "unit": w2["unit"], "cores": c2["procs"], "kind": "port",
+                    ent["cpu_baseline"] = {"value": c2["rate"], "unit": w2["unit"], "cores": c2["procs"], "host_nproc": os.cpu_count(), "kind": "port",
                                            "sample": "first %d units of the same seeded batch, %d single-threaded processes, each slice timed in %d chunks: median chunk rate" % (
                                                c2["sample"], c2["procs"], c2["reps"]),
                                            "single_thread": {"value": c2["single_rate"], "cores": 1, "median_of": c2["reps"]}, "wall_s": c2["wall_s"]}
                 if r.get("table"):
                     ent["generator_table"] = r["table"]
+                if r.get("host_io"):
+                    ent["host_io"] = r["host_io"]
                 line["other_configs"].append(ent)
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
