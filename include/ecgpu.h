@@ -350,6 +350,49 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* pubkeys
 int ecgpu_map_to_curve_batch(ecgpu_ctx* ctx, int curve, const uint8_t* u, int count, uint8_t* out_xy,
                              uint8_t* out_inf, size_t n, int mem);
 
+/* ---- device groups: one call, several GPUs -------------------------------------------------------------------------------
+ * The reference's bulk entry points are single calls over slices (LinearCombinationExt::lincomb_ext, k256 mul.rs:325-340; `&P * &k`
+ * element by element, mul.rs:442-481), so the split over devices lives on this side of the boundary:
+ *   - independent batches: member i of the group takes the contiguous index range ecgpu_shard_range(n, size, i) on its own
+ *     context, host thread and stream; generator tables are per device; NO collective;
+ *   - one split sum (ecgpu_group_msm): every member runs the whole bucket method over its range of terms -> one projective point
+ *     per device -> all-gather of those points (RCCL ncclAllGather over xGMI when the devices are distinct; elliptic-curve addition
+ *     is not an RCCL reduction operator, so all-reduce does not apply) -> the leader (member 0) adds them up.  RCCL is loaded with
+ *     dlopen at the first split sum; a group whose devices are not distinct (two contexts on one card) or a system without RCCL
+ *     gathers through host memory (96 / 144 bytes per device).  ecgpu_group_gather_path says which way the last sum went.
+ * Results are those of the single-context call on the whole batch, byte for byte (for a split sum: the same group element, output
+ * formatted as ecgpu_msm formats it).  A group owns one context per member (ecgpu_group_context: options, generator-table
+ * queries); calls on one group are serialised. */
+typedef struct ecgpu_group ecgpu_group;
+enum { ECGPU_GROUP_NO_RCCL = 1u };            /* ecgpu_group_create flags: gather partial sums through host memory even if RCCL could be used */
+int ecgpu_group_create(ecgpu_group** group, const int* devices, int n_devices, unsigned flags);
+void ecgpu_group_destroy(ecgpu_group* group);
+int ecgpu_group_size(const ecgpu_group* group);
+ecgpu_ctx* ecgpu_group_context(ecgpu_group* group, int index);
+const char* ecgpu_group_last_error(const ecgpu_group* group);
+const char* ecgpu_group_gather_path(const ecgpu_group* group);
+int ecgpu_group_synchronize(ecgpu_group* group);
+/* first / count of part `index` when n elements are cut into `parts` balanced contiguous ranges (needs no device) */
+int ecgpu_shard_range(size_t n, int parts, int index, size_t* first, size_t* count);
+/* ecgpu_mul_batch / ecgpu_lincomb_batch over HOST buffers, split over the group's devices (each member streams its range through
+ * its own host pipeline) */
+int ecgpu_group_mul_batch(ecgpu_group* group, int curve, const uint8_t* scalars, const uint8_t* points, int point_format, uint8_t* out,
+                          int out_format, uint8_t* out_inf, size_t n, unsigned flags);
+int ecgpu_group_lincomb_batch(ecgpu_group* group, int curve, const uint8_t* scalars, const uint8_t* points, int point_format, size_t terms,
+                              uint8_t* out, int out_format, uint8_t* out_inf, size_t n, unsigned flags);
+/* the same over device-resident shards: scalars[i], points[i], out[i], out_inf[i] are pointers into member i's HBM, counts[i] its
+ * number of elements; asynchronous on every member's stream (ecgpu_group_synchronize).  points / out_inf may be NULL. */
+int ecgpu_group_lincomb_sharded(ecgpu_group* group, int curve, const uint8_t* const* scalars, const uint8_t* const* points, int point_format,
+                                size_t terms, uint8_t* const* out, int out_format, uint8_t* const* out_inf, const size_t* counts, unsigned flags);
+/* ONE multi-scalar multiplication over n terms in host memory, split over the group (the 8-GPU form of lincomb_ext over a slice);
+ * `out` is one point in host memory */
+int ecgpu_group_msm(ecgpu_group* group, int curve, const uint8_t* scalars, const uint8_t* points, int point_format, size_t n, uint8_t* out,
+                    int out_format);
+/* the same with the terms already resident: member i sums counts[i] terms at scalars[i] / points[i] in its own HBM; `out` in host
+ * memory */
+int ecgpu_group_msm_sharded(ecgpu_group* group, int curve, const uint8_t* const* scalars, const uint8_t* const* points, int point_format,
+                            const size_t* counts, uint8_t* out, int out_format);
+
 /* ---- synthetic inputs for benchmarks (device memory only) ------------------------------------
  * Fill device buffers with the counter-based streams specified in oracle/synth.py:
  * scalars[i] = reduce(stream 0), points[i] = try-and-increment decompress of streams 1.. .

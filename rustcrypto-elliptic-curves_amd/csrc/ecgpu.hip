@@ -462,8 +462,10 @@ int ecgpu_mul_batch_checked(ecgpu_ctx* c, int curve, const uint8_t* scalars, con
   return lincomb_impl(c, curve, scalars, points, pt_fmt, 1, out, out_fmt, out_inf, scalar_ok, n, mem, flags);
 }
 
-int ecgpu_msm(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t n, uint8_t* out, int out_fmt,
-              int mem) {
+// `mem` is where the inputs live, `out_mem` where the one result point goes (the device group sums host-resident slices into
+// device-resident partial points: group.hip)
+static int msm_impl(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t n, uint8_t* out, int out_fmt,
+                    int mem, int out_mem) {
   if (!c || !out || (n && (!scalars || !points))) return ecgpu_set_err(c, ECGPU_ERR_ARG, "null argument");
   if ((pt_fmt != ECGPU_PT_AFFINE && pt_fmt != ECGPU_PT_PROJECTIVE) || (out_fmt != ECGPU_PT_AFFINE && out_fmt != ECGPU_PT_PROJECTIVE))
     return ecgpu_set_err(c, ECGPU_ERR_ARG, "bad point format");
@@ -472,7 +474,7 @@ int ecgpu_msm(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* po
   Buf bs, bp, bo;
   int rc;
   if (n == 0) {                              // the empty sum is the identity: affine zeros, projective (0 : 1 : 0)
-    if (mem == ECGPU_MEM_HOST) {
+    if (out_mem == ECGPU_MEM_HOST) {
       memset(out, 0, pout);
       if (out_fmt == ECGPU_PT_PROJECTIVE) out[2 * nb - 1] = 1;
       return ECGPU_OK;
@@ -499,18 +501,23 @@ int ecgpu_msm(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* po
     std::vector<uint8_t> ones(parts * nb, 0);
     for (size_t i = 0; i < parts; i++) ones[i * nb + nb - 1] = 1;
     HIPCHK(c, hipMemcpyAsync(c->stage[4], ones.data(), parts * nb, hipMemcpyHostToDevice, c->stream));
-    if ((rc = buf_out(c, bo, 2, out, pout, mem))) return rc;
+    if ((rc = buf_out(c, bo, 2, out, pout, out_mem))) return rc;
     if ((rc = ops->msm(c, (const uint32_t*)c->stage[4], (const uint32_t*)partial, ECGPU_PT_PROJECTIVE, parts, (uint32_t*)bo.dev, out_fmt))) return rc;
     if ((rc = buf_finish(c, bo))) return rc;
-    return finish_host(c, mem);              // (`ones` lives until the stream has been synchronised here)
+    return finish_host(c, ECGPU_MEM_HOST);   // `ones` lives until the stream has been synchronised here
   }
   if ((rc = buf_in(c, bs, 0, scalars, n * nb, mem))) return rc;
   if ((rc = buf_in(c, bp, 1, points, n * pin, mem))) return rc;
-  if ((rc = buf_out(c, bo, 2, out, pout, mem))) return rc;
+  if ((rc = buf_out(c, bo, 2, out, pout, out_mem))) return rc;
   if ((rc = ops->msm(c, (const uint32_t*)bs.dev, (const uint32_t*)bp.dev, pt_fmt, n, (uint32_t*)bo.dev, out_fmt))) return rc;
   if ((rc = buf_finish(c, bo))) return rc;
-  return finish_host(c, mem);
+  return finish_host(c, (mem == ECGPU_MEM_HOST || out_mem == ECGPU_MEM_HOST) ? ECGPU_MEM_HOST : ECGPU_MEM_DEVICE);    // staged inputs must have left the host buffers
 }
+int ecgpu_msm(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t n, uint8_t* out, int out_fmt,
+              int mem) {
+  return msm_impl(c, curve, scalars, points, pt_fmt, n, out, out_fmt, mem, mem);
+}
+
 
 // ---------------------------------------------------------------------------------------------
 int ecgpu_validate_scalars(ecgpu_ctx* c, int curve, const uint8_t* scalars, uint8_t* ok, size_t n, int mem) {
@@ -769,3 +776,9 @@ int ecgpu_synth_points(ecgpu_ctx* c, int curve, uint64_t seed, uint64_t first, u
 }
 
 }  // extern "C"
+
+// internal (C++ linkage: not exported, csrc/ecgpu.map): ecgpu_msm with the inputs and the result in different kinds of memory
+int ecgpuint_msm_mixed(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t n, uint8_t* out, int out_fmt,
+                       int mem_in, int mem_out) {
+  return msm_impl(c, curve, scalars, points, pt_fmt, n, out, out_fmt, mem_in, mem_out);
+}

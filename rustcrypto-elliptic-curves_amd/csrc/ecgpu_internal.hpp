@@ -122,3 +122,6 @@ int ecgpu_msm_p384(ecgpu_ctx* c, const uint32_t* sc, const uint32_t* pts, int pt
 const ecgpu_curve_ops* ecgpu_ops_k256();
 const ecgpu_curve_ops* ecgpu_ops_p256();
 const ecgpu_curve_ops* ecgpu_ops_p384();
+// ecgpu_msm with the inputs and the result in different kinds of memory (ecgpu.hip; used by the device group, group.hip)
+int ecgpuint_msm_mixed(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t n, uint8_t* out, int out_fmt,
+                       int mem_in, int mem_out);

@@ -50,6 +50,15 @@ def host_chunk_schedule(n: int, pass_units: int) -> list:
     return list(arr[:cnt])
 
 
+def shard_range(n: int, parts: int, index: int) -> tuple:
+    """(first, count) of part `index` of n elements cut into `parts` balanced contiguous ranges (ecgpu_shard_range; no device needed)"""
+    lib = load_library()
+    a, b = ctypes.c_size_t(), ctypes.c_size_t()
+    if lib.ecgpu_shard_range(n, parts, index, ctypes.byref(a), ctypes.byref(b)) != 0:
+        raise ValueError("shard_range(%d, %d, %d)" % (n, parts, index))
+    return a.value, b.value
+
+
 class EcgpuError(RuntimeError):
     pass
 
@@ -89,6 +98,24 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.ecgpu_host_free.argtypes = [vp, vp]
     lib.ecgpu_debug_workspace.argtypes = [vp, i, vp, sz, ctypes.POINTER(sz)]
     lib.ecgpu_host_chunk_schedule.argtypes = [sz, sz, ctypes.POINTER(sz), sz]
+    pp = ctypes.POINTER(vp)
+    lib.ecgpu_group_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i), i, ctypes.c_uint]
+    lib.ecgpu_group_destroy.argtypes = [vp]
+    lib.ecgpu_group_destroy.restype = None
+    lib.ecgpu_group_size.argtypes = [vp]
+    lib.ecgpu_group_context.argtypes = [vp, i]
+    lib.ecgpu_group_context.restype = vp
+    lib.ecgpu_group_last_error.argtypes = [vp]
+    lib.ecgpu_group_last_error.restype = ctypes.c_char_p
+    lib.ecgpu_group_gather_path.argtypes = [vp]
+    lib.ecgpu_group_gather_path.restype = ctypes.c_char_p
+    lib.ecgpu_group_synchronize.argtypes = [vp]
+    lib.ecgpu_shard_range.argtypes = [sz, i, i, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.ecgpu_group_mul_batch.argtypes = [vp, i, u8p, u8p, i, u8p, i, u8p, sz, ctypes.c_uint]
+    lib.ecgpu_group_lincomb_batch.argtypes = [vp, i, u8p, u8p, i, sz, u8p, i, u8p, sz, ctypes.c_uint]
+    lib.ecgpu_group_lincomb_sharded.argtypes = [vp, i, pp, pp, i, sz, pp, i, pp, ctypes.POINTER(sz), ctypes.c_uint]
+    lib.ecgpu_group_msm.argtypes = [vp, i, u8p, u8p, i, sz, u8p, i]
+    lib.ecgpu_group_msm_sharded.argtypes = [vp, i, pp, pp, i, ctypes.POINTER(sz), u8p, i]
     lib.ecgpu_timer_start.argtypes = [vp]
     lib.ecgpu_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.ecgpu_field_op_batch.argtypes = [vp, i, i, u8p, u8p, u8p, sz, i]
@@ -123,7 +150,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
                  "ecgpu_from_bytes_batch", "ecgpu_host_alloc", "ecgpu_host_free", "ecgpu_schnorr_verify_batch",
                  "ecgpu_ecdsa_recover_batch", "ecgpu_map_to_curve_batch", "ecgpu_use_own_stream", "ecgpu_last_error_copy",
                  "ecgpu_set_option", "ecgpu_get_option", "ecgpu_fb_table_bytes", "ecgpu_sec1_encode_batch", "ecgpu_sec1_decode_batch",
-                 "ecgpu_ecdh_batch", "ecgpu_debug_workspace", "ecgpu_host_chunk_schedule"):
+                 "ecgpu_ecdh_batch", "ecgpu_debug_workspace", "ecgpu_host_chunk_schedule", "ecgpu_group_create", "ecgpu_group_size",
+                 "ecgpu_group_synchronize", "ecgpu_shard_range", "ecgpu_group_mul_batch", "ecgpu_group_lincomb_batch", "ecgpu_group_lincomb_sharded",
+                 "ecgpu_group_msm", "ecgpu_group_msm_sharded"):
         getattr(lib, name).restype = ctypes.c_int
     if path is None:
         _lib = lib
@@ -140,6 +169,9 @@ EXPORTED_SYMBOLS = (
     "ecgpu_point_eq_batch", "ecgpu_mul_batch_checked", "ecgpu_lincomb_batch_checked",
     "ecgpu_use_own_stream", "ecgpu_last_error_copy", "ecgpu_set_option", "ecgpu_get_option", "ecgpu_fb_table_bytes",
     "ecgpu_sec1_encode_batch", "ecgpu_sec1_decode_batch", "ecgpu_ecdh_batch", "ecgpu_debug_workspace", "ecgpu_host_chunk_schedule",
+    "ecgpu_group_create", "ecgpu_group_destroy", "ecgpu_group_size", "ecgpu_group_context", "ecgpu_group_last_error", "ecgpu_group_gather_path",
+    "ecgpu_group_synchronize", "ecgpu_shard_range", "ecgpu_group_mul_batch", "ecgpu_group_lincomb_batch", "ecgpu_group_lincomb_sharded",
+    "ecgpu_group_msm", "ecgpu_group_msm_sharded",
 )
 
 
@@ -546,3 +578,111 @@ class Curve:
 
     def synth_points_device(self, d_out, n: int, seed: int, first_index: int = 0):
         self.ctx.check(self.ctx.lib.ecgpu_synth_points(self.ctx.handle, self.id, seed, first_index, _ptr(d_out)[0], n))
+
+
+GROUP_NO_RCCL = 1
+
+
+class _BorrowedContext(Context):
+    """a group member's context (owned by the group: never destroyed from here)"""
+
+    def __init__(self, lib, handle, device):
+        self.lib, self.handle, self.device, self._pinned = lib, ctypes.c_void_p(handle), device, []
+
+    def close(self):
+        for p in self._pinned:
+            self.lib.ecgpu_host_free(self.handle, p)
+        self._pinned = []
+        self.handle = ctypes.c_void_p()
+
+
+class Group:
+    """Device group (include/ecgpu.h, "device groups"): the single-call entry points split over several GPUs - contiguous index
+    ranges for independent batches (no collective), per-device bucket method + all-gather of one point per device + fold for one
+    split sum.  `devices` may repeat a device (two contexts on one card)."""
+
+    def __init__(self, devices: Sequence[int], flags: int = 0):
+        self.lib = load_library()
+        self.handle = ctypes.c_void_p()
+        arr = (ctypes.c_int * len(devices))(*devices)
+        rc = self.lib.ecgpu_group_create(ctypes.byref(self.handle), arr, len(devices), flags)
+        if rc != 0:
+            raise EcgpuError(f"ecgpu_group_create({list(devices)}) failed with {rc} (no usable gfx950 GPU? there is no CPU fallback)")
+        self.devices = list(devices)
+        self.size = len(devices)
+        self.members = [_BorrowedContext(self.lib, self.lib.ecgpu_group_context(self.handle, i), d) for i, d in enumerate(devices)]
+
+    def close(self):
+        if self.handle:
+            for m in self.members:
+                m.close()
+            self.lib.ecgpu_group_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise EcgpuError(f"ecgpu group error {rc}: {self.lib.ecgpu_group_last_error(self.handle).decode()}")
+
+    def context(self, index: int) -> Context:
+        return self.members[index]
+
+    def gather_path(self) -> str:
+        return self.lib.ecgpu_group_gather_path(self.handle).decode()
+
+    def synchronize(self):
+        self.check(self.lib.ecgpu_group_synchronize(self.handle))
+
+    def lincomb(self, curve, scalars, points, terms: int = 1, point_format: int = AFFINE, out_format: int = AFFINE, flags: int = 0, out=None, out_inf=None):
+        cid = CURVE_IDS[curve] if isinstance(curve, str) else int(curve)
+        nb = FIELD_BYTES[cid]
+        s = _as_host(scalars, nb)
+        n = len(s) // terms
+        pw, ow = (3 if point_format == PROJECTIVE else 2) * nb, (3 if out_format == PROJECTIVE else 2) * nb
+        p = _as_host(points, pw) if points is not None else None
+        if len(s) % terms or (p is not None and len(p) != n * terms):
+            raise ValueError("scalars and points differ in count")
+        out = _host_out(n, ow) if out is None else out
+        inf = np.zeros(n, dtype=np.uint8) if out_inf is None else out_inf
+        self.check(self.lib.ecgpu_group_lincomb_batch(self.handle, cid, _ptr(s)[0], _ptr(p)[0], point_format, terms, _ptr(out)[0], out_format, _ptr(inf)[0], n, flags))
+        return (out, inf) if out_format == AFFINE else out
+
+    def mul(self, curve, scalars, points, **kw):
+        return self.lincomb(curve, scalars, points, 1, **kw)
+
+    def msm(self, curve, scalars, points, point_format: int = AFFINE, out_format: int = AFFINE) -> np.ndarray:
+        cid = CURVE_IDS[curve] if isinstance(curve, str) else int(curve)
+        nb = FIELD_BYTES[cid]
+        s = _as_host(scalars, nb)
+        p = _as_host(points, (3 if point_format == PROJECTIVE else 2) * nb)
+        if len(p) != len(s):
+            raise ValueError("scalars and points differ in count")
+        out = _host_out(1, (3 if out_format == PROJECTIVE else 2) * nb)
+        self.check(self.lib.ecgpu_group_msm(self.handle, cid, _ptr(s)[0], _ptr(p)[0], point_format, len(s), _ptr(out)[0], out_format))
+        return out[0]
+
+    @staticmethod
+    def _ptr_array(xs):
+        return (ctypes.c_void_p * len(xs))(*[(_ptr(x)[0].value if x is not None else None) for x in xs])
+
+    def lincomb_sharded(self, curve, d_scalars, d_points, d_out, counts, terms: int = 1, point_format: int = AFFINE, out_format: int = AFFINE, d_out_inf=None,
+                        flags: int = 0):
+        """device-resident shards (lists of torch tensors / device pointers, one per member); asynchronous: Group.synchronize()"""
+        cid = CURVE_IDS[curve] if isinstance(curve, str) else int(curve)
+        cnt = (ctypes.c_size_t * self.size)(*counts)
+        self.check(self.lib.ecgpu_group_lincomb_sharded(self.handle, cid, self._ptr_array(d_scalars), self._ptr_array(d_points) if d_points is not None else None,
+                                                        point_format, terms, self._ptr_array(d_out), out_format,
+                                                        self._ptr_array(d_out_inf) if d_out_inf is not None else None, cnt, flags))
+
+    def msm_sharded(self, curve, d_scalars, d_points, counts, point_format: int = AFFINE, out_format: int = AFFINE) -> np.ndarray:
+        cid = CURVE_IDS[curve] if isinstance(curve, str) else int(curve)
+        nb = FIELD_BYTES[cid]
+        cnt = (ctypes.c_size_t * self.size)(*counts)
+        out = _host_out(1, (3 if out_format == PROJECTIVE else 2) * nb)
+        self.check(self.lib.ecgpu_group_msm_sharded(self.handle, cid, self._ptr_array(d_scalars), self._ptr_array(d_points), point_format, cnt, _ptr(out)[0], out_format))
+        return out[0]

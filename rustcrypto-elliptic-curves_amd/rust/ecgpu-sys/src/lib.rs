@@ -12,6 +12,10 @@ use core::ffi::{c_char, c_int, c_uint, c_void};
 pub struct ecgpu_ctx {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct ecgpu_group {
+    _private: [u8; 0],
+}
 
 pub const ECGPU_K256: c_int = 0;
 pub const ECGPU_P256: c_int = 1;
@@ -51,6 +55,8 @@ pub const ECGPU_OPT_MSM_ROUNDS: c_int = 5;
 pub const ECGPU_OPT_K256_WAVES: c_int = 6;
 pub const ECGPU_OPT_FB_MEMORY_BUDGET: c_int = 7;
 pub const ECGPU_OPT_COUNT_: c_int = 8;
+/// `ecgpu_group_create` flag: gather the partial sums of a split sum through host memory even where RCCL could be used
+pub const ECGPU_GROUP_NO_RCCL: c_uint = 1;
 
 #[link(name = "ecgpu")]
 extern "C" {
@@ -108,6 +114,24 @@ extern "C" {
     pub fn ecgpu_schnorr_verify_batch(ctx: *mut ecgpu_ctx, curve: c_int, pubkeys_x: *const u8, sig_rs: *const u8, challenges: *const u8, ok: *mut u8, n: usize,
                                       mem: c_int) -> c_int;
     pub fn ecgpu_map_to_curve_batch(ctx: *mut ecgpu_ctx, curve: c_int, u: *const u8, count: c_int, out_xy: *mut u8, out_inf: *mut u8, n: usize, mem: c_int) -> c_int;
+    pub fn ecgpu_group_create(group: *mut *mut ecgpu_group, devices: *const c_int, n_devices: c_int, flags: c_uint) -> c_int;
+    pub fn ecgpu_group_destroy(group: *mut ecgpu_group);
+    pub fn ecgpu_group_size(group: *const ecgpu_group) -> c_int;
+    pub fn ecgpu_group_context(group: *mut ecgpu_group, index: c_int) -> *mut ecgpu_ctx;
+    pub fn ecgpu_group_last_error(group: *const ecgpu_group) -> *const c_char;
+    pub fn ecgpu_group_gather_path(group: *const ecgpu_group) -> *const c_char;
+    pub fn ecgpu_group_synchronize(group: *mut ecgpu_group) -> c_int;
+    pub fn ecgpu_shard_range(n: usize, parts: c_int, index: c_int, first: *mut usize, count: *mut usize) -> c_int;
+    pub fn ecgpu_group_mul_batch(group: *mut ecgpu_group, curve: c_int, scalars: *const u8, points: *const u8, point_format: c_int, out: *mut u8, out_format: c_int,
+                                 out_inf: *mut u8, n: usize, flags: c_uint) -> c_int;
+    pub fn ecgpu_group_lincomb_batch(group: *mut ecgpu_group, curve: c_int, scalars: *const u8, points: *const u8, point_format: c_int, terms: usize, out: *mut u8,
+                                     out_format: c_int, out_inf: *mut u8, n: usize, flags: c_uint) -> c_int;
+    pub fn ecgpu_group_lincomb_sharded(group: *mut ecgpu_group, curve: c_int, scalars: *const *const u8, points: *const *const u8, point_format: c_int, terms: usize,
+                                       out: *const *mut u8, out_format: c_int, out_inf: *const *mut u8, counts: *const usize, flags: c_uint) -> c_int;
+    pub fn ecgpu_group_msm(group: *mut ecgpu_group, curve: c_int, scalars: *const u8, points: *const u8, point_format: c_int, n: usize, out: *mut u8,
+                           out_format: c_int) -> c_int;
+    pub fn ecgpu_group_msm_sharded(group: *mut ecgpu_group, curve: c_int, scalars: *const *const u8, points: *const *const u8, point_format: c_int,
+                                   counts: *const usize, out: *mut u8, out_format: c_int) -> c_int;
     pub fn ecgpu_synth_scalars(ctx: *mut ecgpu_ctx, curve: c_int, seed: u64, first_index: u64, d_scalars: *mut u8, n: usize) -> c_int;
     pub fn ecgpu_synth_points(ctx: *mut ecgpu_ctx, curve: c_int, seed: u64, first_index: u64, d_points_xy: *mut u8, n: usize) -> c_int;
 }
@@ -357,5 +381,64 @@ impl Context {
     }
     pub fn set_option(&self, option: c_int, value: i64) -> Result<(), Error> { self.check(unsafe { ecgpu_set_option(self.0, option, value) }) }
     pub fn use_own_stream(&self) -> Result<(), Error> { self.check(unsafe { ecgpu_use_own_stream(self.0) }) }
+    /// All later launches go to the caller's `hipStream_t`.  Since library version 0.3 a NULL handle is the legacy default stream
+    /// itself, as for every HIP API - it is NOT "back to the context's own stream" (that is `use_own_stream`).
+    ///
+    /// # Safety
+    /// `hip_stream` must be NULL or a live stream of this context's device, and must outlive its use by the context.
+    pub unsafe fn set_stream(&self, hip_stream: *mut c_void) -> Result<(), Error> { self.check(ecgpu_set_stream(self.0, hip_stream)) }
+    /// The legacy default stream (handle 0): ordered with every blocking stream of the process.
+    pub fn use_default_stream(&self) -> Result<(), Error> { self.check(unsafe { ecgpu_set_stream(self.0, core::ptr::null_mut()) }) }
     pub fn synchronize(&self) -> Result<(), Error> { self.check(unsafe { ecgpu_synchronize(self.0) }) }
+}
+
+/// A device group (`ecgpu_group_create`): the single-call entry points split over several GPUs.  Independent batches take
+/// contiguous index ranges per device (no collective); one split sum runs the bucket method per device, all-gathers one point per
+/// device (RCCL over xGMI when the devices are distinct) and folds on the first device.  Host buffers only.
+pub struct Group(*mut ecgpu_group);
+unsafe impl Send for Group {}
+unsafe impl Sync for Group {}          // calls on one group are serialised by the library
+
+impl Drop for Group {
+    fn drop(&mut self) {
+        unsafe { ecgpu_group_destroy(self.0) }
+    }
+}
+
+impl Group {
+    /// `devices` may repeat a device (several contexts on one card).
+    pub fn new(devices: &[i32], flags: c_uint) -> Result<Self, Error> {
+        let mut p = core::ptr::null_mut();
+        let rc = unsafe { ecgpu_group_create(&mut p, devices.as_ptr(), devices.len() as c_int, flags) };
+        if rc == ECGPU_OK { Ok(Group(p)) } else { Err(Error { code: rc, message: "ecgpu_group_create failed (no gfx950 device? there is no CPU fallback)".into() }) }
+    }
+    pub fn raw(&self) -> *mut ecgpu_group { self.0 }
+    pub fn size(&self) -> usize { unsafe { ecgpu_group_size(self.0) as usize } }
+    fn check(&self, rc: c_int) -> Result<(), Error> {
+        if rc == ECGPU_OK { return Ok(()); }
+        let msg = unsafe { std::ffi::CStr::from_ptr(ecgpu_group_last_error(self.0)) }.to_string_lossy().into_owned();
+        Err(Error { code: rc, message: msg })
+    }
+    /// `Context::lincomb` over the group: n independent linear combinations, member i computes the range `ecgpu_shard_range(n, size, i)`.
+    #[allow(clippy::too_many_arguments)]
+    pub fn lincomb(&self, curve: c_int, scalars: &[u8], points: Option<&[u8]>, point_format: c_int, terms: usize, out_format: c_int, flags: c_uint)
+                   -> Result<(Vec<u8>, Vec<u8>), Error> {
+        let nb = Context::field_bytes(curve);
+        Context::arg(nb != 0 && terms >= 1 && scalars.len() % (nb * terms) == 0)?;
+        let n = scalars.len() / (nb * terms);
+        Context::arg(points.map_or(terms == 1, |p| p.len() == n * terms * Context::pt_bytes(nb, point_format)))?;
+        let mut out = vec![0u8; n * Context::pt_bytes(nb, out_format)];
+        let mut inf = vec![0u8; n];
+        let pp = points.map_or(core::ptr::null(), |p| p.as_ptr());
+        self.check(unsafe { ecgpu_group_lincomb_batch(self.0, curve, scalars.as_ptr(), pp, point_format, terms, out.as_mut_ptr(), out_format, inf.as_mut_ptr(), n, flags) })?;
+        Ok((out, inf))
+    }
+    /// One sum over all terms, split over the group's devices: the 8-GPU form of `lincomb_ext` over a slice.
+    pub fn msm(&self, curve: c_int, scalars: &[u8], points: &[u8], point_format: c_int, out_format: c_int) -> Result<Vec<u8>, Error> {
+        let nb = Context::field_bytes(curve);
+        Context::arg(nb != 0 && scalars.len() % nb == 0 && points.len() == scalars.len() / nb * Context::pt_bytes(nb, point_format))?;
+        let mut out = vec![0u8; Context::pt_bytes(nb, out_format)];
+        self.check(unsafe { ecgpu_group_msm(self.0, curve, scalars.as_ptr(), points.as_ptr(), point_format, scalars.len() / nb, out.as_mut_ptr(), out_format) })?;
+        Ok(out)
+    }
 }

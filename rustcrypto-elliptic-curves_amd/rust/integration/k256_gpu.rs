@@ -6,7 +6,7 @@
 //! (field.rs:118-120, field_5x52.rs:96-131), `Scalar::to_bytes` (scalar.rs:94-96); nothing here depends on the in-memory
 //! layout of the types (which is not ABI-stable, field_impl.rs:23-28).
 use alloc::vec::Vec;
-use ecgpu_sys::{Context, Error, ECGPU_EXACT_REFERENCE, ECGPU_K256, ECGPU_PT_AFFINE, ECGPU_PT_PROJECTIVE};
+use ecgpu_sys::{Context, Error, Group, ECGPU_EXACT_REFERENCE, ECGPU_K256, ECGPU_PT_AFFINE, ECGPU_PT_PROJECTIVE};
 
 use crate::{AffinePoint, FieldBytes, ProjectivePoint, Scalar};
 use super::FieldElement;
@@ -52,13 +52,25 @@ pub fn mul_batch(gpu: &Context, points: &[ProjectivePoint], scalars: &[Scalar]) 
 }
 
 /// `LinearCombinationExt<[(ProjectivePoint, Scalar)]>::lincomb_ext` (mul.rs:325-340) at MSM scale: one bucket-method sum
-/// over the whole slice.  The group element is that of the CPU path; the representative is (x : y : 1).
-pub fn lincomb_ext_gpu(gpu: &Context, points_and_scalars: &[(ProjectivePoint, Scalar)]) -> Result<ProjectivePoint, Error> {
+/// over the whole slice, split over the devices of a `Group` (every device sums a contiguous range of the terms, one point per
+/// device is all-gathered - RCCL over xGMI - and folded on the first device; a group of one device is the single-GPU call).
+/// The group element is that of the CPU path; the representative is (x : y : 1).
+pub fn lincomb_ext_gpu(gpus: &Group, points_and_scalars: &[(ProjectivePoint, Scalar)]) -> Result<ProjectivePoint, Error> {
     let s = put_scalars(points_and_scalars.iter().map(|(_, k)| k));
     let mut p = Vec::with_capacity(96 * points_and_scalars.len());
     for (q, _) in points_and_scalars { put_projective(&mut p, q); }
-    let out = gpu.msm(ECGPU_K256, &s, &p, ECGPU_PT_PROJECTIVE, ECGPU_PT_PROJECTIVE)?;
+    let out = gpus.msm(ECGPU_K256, &s, &p, ECGPU_PT_PROJECTIVE, ECGPU_PT_PROJECTIVE)?;
     Ok(get_projective(&out))
+}
+
+/// Bulk `&ProjectivePoint * &Scalar` over a `Group`: contiguous index ranges per device, no collective.
+pub fn mul_batch_group(gpus: &Group, points: &[ProjectivePoint], scalars: &[Scalar]) -> Result<Vec<AffinePoint>, Error> {
+    assert_eq!(points.len(), scalars.len());
+    let s = put_scalars(scalars.iter());
+    let mut p = Vec::with_capacity(96 * points.len());
+    for q in points { put_projective(&mut p, q); }
+    let (out, inf) = gpus.lincomb(ECGPU_K256, &s, Some(&p), ECGPU_PT_PROJECTIVE, 1, ECGPU_PT_AFFINE, 0)?;
+    Ok(out.chunks_exact(64).zip(inf.iter()).map(|(xy, i)| get_affine(xy, *i)).collect())
 }
 
 /// `LinearCombination::lincomb(x, k, y, l)` (mul.rs:313-323) for many independent pairs: out[i] = x_i k_i + y_i l_i.

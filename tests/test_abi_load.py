@@ -108,3 +108,31 @@ def test_host_chunk_schedule():
         if len(s) > 1:
             assert s[-1] <= max(p // 8, 0) + p // 16 or s[-1] < 2 * (p // 8), (n, pass_units, s)   # short drain
             assert all(x >= p // 16 for x in s), (n, pass_units, s)             # no crumbs
+
+
+def test_shard_range_arithmetic():
+    """ecgpu_shard_range (the index ranges a device group hands its members): balanced, contiguous, disjoint,
+    covering - including n < parts and n = 0 - and the same as the Python launcher's parallel.shard_range for equal shares."""
+    if not os.path.exists(ecgpu.LIB_PATH):
+        pytest.skip("libecgpu.so not built")
+    import random
+    rng = random.Random(11)
+    cases = [(0, 1), (0, 8), (5, 8), (8, 8), (9, 8), ((1 << 26), 8), ((1 << 23) + 777, 2), ((1 << 22) + 12345, 2), (1, 64)]
+    cases += [(rng.randrange(0, 1 << 40), rng.randrange(1, 65)) for _ in range(200)]
+    for n, k in cases:
+        nxt, sizes = 0, []
+        for i in range(k):
+            lo, cnt = ecgpu.shard_range(n, k, i)
+            assert lo == nxt
+            nxt = lo + cnt
+            sizes.append(cnt)
+        assert nxt == n and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    with pytest.raises(ValueError):
+        ecgpu.shard_range(10, 0, 0)
+    with pytest.raises(ValueError):
+        ecgpu.shard_range(10, 4, 4)
+    from ecgpu import parallel
+    for world in (1, 2, 4, 8):
+        for rank in range(world):
+            lo, hi = parallel.shard_range((1 << 24) + 5, rank, world)
+            assert (lo, hi - lo) == ecgpu.shard_range((1 << 24) + 5, world, rank)
