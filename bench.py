@@ -616,6 +616,94 @@ def roofline_for(name, res, schedule, peak_meas, pair_meas, world=1):
     return r
 
 
+def run_inproc(args):
+    """--inproc: all N GPUs from ONE process through the library's device group (include/ecgpu.h "device groups", csrc/group.hip) -
+    what a caller on the reference's side of the boundary gets from one call: per-device contexts, host threads and streams,
+    contiguous index ranges, no collective for the independent batches; per-device bucket method, RCCL all-gather of one point per
+    device and a fold on the first device for the split sum.  Inputs resident in each device's HBM before the timed region, as in the
+    one-process-per-GPU path; the same metric, the same parity rules (every member's first and last units against the C oracle,
+    the split sum over ALL terms against the closed form).  --same-device puts all members on device 0 (rehearsal on a one-GPU box)."""
+    import numpy as np
+    import torch
+    import ecgpu
+    from oracle import coracle as CO
+    from oracle import ecmodel as M
+    wl = WORKLOADS[args.workload]
+    if wl.get("ecdsa"):
+        raise SystemExit("--inproc runs the BASELINE configs (variable base, fixed base, MSM)")
+    k = args.gpus
+    n = 1 << (args.log2n or wl["log2n"])
+    devices = [0] * k if args.same_device else list(range(k))
+    g = ecgpu.Group(devices)
+    nb = ecgpu.FIELD_BYTES[wl["cid"]]
+    d_s, d_p, d_o, d_i = [], [], [], []
+    for i, dv in enumerate(devices):
+        dev = torch.device("cuda", dv)
+        cv = g.context(i).curve(wl["curve"])
+        first = i * n
+        s = torch.empty((n, nb), dtype=torch.uint8, device=dev)
+        cv.synth_scalars_device(s, n, SEED, first)
+        p = None
+        if wl["msm"]:
+            p = torch.empty((n, 2 * nb), dtype=torch.uint8, device=dev)
+            v = torch.from_numpy(structured_point_scalars(first, n)).to(dev)
+            cv.mul_device(v, None, p, n)
+            g.context(i).synchronize()
+            del v
+        elif not wl["fixed"]:
+            p = torch.empty((n, 2 * nb), dtype=torch.uint8, device=dev)
+            cv.synth_points_device(p, n, SEED, first)
+        d_s.append(s); d_p.append(p)
+        d_o.append(torch.empty((n, 2 * nb), dtype=torch.uint8, device=dev))
+        d_i.append(torch.empty((n,), dtype=torch.uint8, device=dev))
+    g.synchronize()
+    counts = [n] * k
+    result = [None]
+
+    def step():
+        if wl["msm"]:
+            result[0] = g.msm_sharded(wl["curve"], d_s, d_p, counts)
+        else:
+            g.lincomb_sharded(wl["curve"], d_s, None if wl["fixed"] else d_p, d_o, counts, d_out_inf=d_i)
+
+    for _ in range(max(1, args.warmup)):             # the first call builds per-device tables / workspaces (and the RCCL communicator)
+        step()
+    g.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    g.synchronize()
+    elapsed = time.perf_counter() - t0
+    parity, checked = True, []
+    if wl["msm"]:
+        t_total = 0
+        for i in range(k):
+            t_total += msm_expected_scalar(CO.synth_scalars(0, n, SEED, i * n), i * n, M.K256.n)
+        want = M.affine_mul(M.K256, t_total % M.K256.n, (M.K256.gx, M.K256.gy))
+        parity &= bytes(result[0]) == (bytes(64) if want is None else M.i2b(M.K256, want[0]) + M.i2b(M.K256, want[1]))
+        checked.append("sum over all %d terms equals (sum k_i (a0 + i d) mod n) G for the structured points P_i = (a0 + i d) G" % (k * n))
+    else:
+        cl = min(CHECK_LEN if wl["curve"] != "p384" else CHECK_LEN // 4, n // 2)
+        for i in range(k):
+            for lo in (0, n - cl):
+                s = d_s[i][lo:lo + cl].cpu().numpy()
+                p = None if d_p[i] is None else d_p[i][lo:lo + cl].cpu().numpy()
+                got = torch.cat([d_o[i][lo:lo + cl], d_i[i][lo:lo + cl, None]], dim=1).cpu().numpy().tobytes()
+                parity &= (got == CO.lincomb_batch(wl["cid"], s, p, threads=8).tobytes())
+        checked.append("first and last %d units of every member's range against the C oracle" % cl)
+    line = {"metric": wl["metric"], "value": k * n * args.steps / elapsed, "unit": wl["unit"], "n_gpus": k, "steps": args.steps, "warmup": max(1, args.warmup),
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": wl["desc"] % (args.log2n or wl["log2n"]), "units_per_gpu_per_step": n,
+                       "parallelism": ("in-process device group over devices %s (ecgpu_group_*): " % devices) +
+                                      ("per-device bucket method, gather of one projective point per device (%s), fold on device %d" % (g.gather_path(), devices[0])
+                                       if wl["msm"] else "contiguous index ranges, one host thread + context + stream per device, no collective")},
+            "parity_ok": bool(parity), "parity_checked": checked}
+    g.close()
+    print(json.dumps(line), flush=True)
+    if not parity:
+        raise SystemExit("PARITY FAILURE: GPU output differs from the CPU oracle / closed form")
+
+
 def cpu_plan(wl, n, cpu_sample, procs):
     per_proc = {"k256": 61440, "p256": 7680, "p384": 3840}[wl["curve"]]
     if wl.get("ecdsa"):
@@ -642,7 +730,12 @@ def main():
                          "(RCCL all_gather_into_tensor on device tensors + the device fold) on a one-GPU box")
     ap.add_argument("--schedule", choices=["fast", "ref"], default="fast",
                     help="fast = throughput schedule (affine result specified); ref = reference-faithful schedule (exact XYZ)")
+    ap.add_argument("--inproc", action="store_true",
+                    help="drive all --gpus N devices from THIS process through the library's device group (ecgpu_group_*) instead of one process per GPU")
+    ap.add_argument("--same-device", action="store_true", help="--inproc: put all group members on device 0 (rehearsal on a one-GPU box)")
     args = ap.parse_args()
+    if args.inproc:
+        return run_inproc(args)
     maybe_launch_ranks(args)
     # Rank 0 prints ONE JSON line on stdout.  Native libraries print there too (RCCL's version banner, gloo's connection
     # lines), so file descriptor 1 points at stderr for the duration of the run and is restored for the line itself.

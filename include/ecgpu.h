@@ -155,7 +155,10 @@ typedef enum ecgpu_option {
   ECGPU_OPT_FB_MEMORY_BUDGET = 7, /* bytes of device memory the generator tables of ONE curve may take in this context,
                                      0 = no budget [0].  A table that would exceed it is treated exactly like one whose
                                      allocation failed: the call steps down to the next narrower width. */
-  ECGPU_OPT_COUNT_ = 8
+  ECGPU_OPT_LINCOMB_TERM_BY_TERM = 8, /* 1: combinations of 3 .. 1024 terms run as one reference-schedule multiplication per term folded with
+                                     the complete addition (the form used until round 4: measurements, cross-checks), 0: the shared-doubling
+                                     schedule of csrc/straus.hpp [0] */
+  ECGPU_OPT_COUNT_ = 9
 } ecgpu_option;
 int ecgpu_set_option(ecgpu_ctx* ctx, int option, int64_t value);
 int ecgpu_get_option(ecgpu_ctx* ctx, int option, int64_t* value);
@@ -238,9 +241,12 @@ int ecgpu_mul_batch_checked(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, c
 
 /* n independent linear combinations of `terms` terms each:
  *   out[i] = sum_j scalars[i*terms + j] * points[i*terms + j]
- * terms = 1, 2: throughput or exact-reference schedules as for ecgpu_mul_batch.  3 <= terms <= 1024: one reference
- * multiplication per term folded with the complete addition - the group element is specified, a PROJECTIVE result
- * is a valid representative but not the reference's (X, Y, Z), ECGPU_EXACT_REFERENCE is refused.
+ * terms = 1, 2: throughput or exact-reference schedules as for ecgpu_mul_batch.  3 <= terms <= 1024: groups of up to 16 terms share
+ * the doublings of one window loop over per-term affine tables (csrc/straus.hpp; ~890 instead of ~2 000 field multiplications per
+ * secp256k1 term) - the group element is specified, a PROJECTIVE result is the representative (x : y : 1).  With
+ * ECGPU_EXACT_REFERENCE secp256k1 runs the reference's own interleaved schedule (k256 mul.rs:342-393) for any length up to 1024, so the
+ * (X, Y, Z) of lincomb_ext over a slice is exact; for P-256 / P-384 it is refused above two terms (their lincomb over slices lives in
+ * the external elliptic-curve crate: nothing in tree to be exact to).
  * LinearCombination::lincomb (terms = 2) / LinearCombinationExt::lincomb_ext (k256 mul.rs:313-393;
  * primeorder default projective.rs:415-420). */
 int ecgpu_lincomb_batch(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points,

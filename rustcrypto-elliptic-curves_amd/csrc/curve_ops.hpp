@@ -8,6 +8,7 @@
 #include "sec1_kernels.hpp"
 #include "schnorr_kernels.hpp"
 #include "h2c_kernels.hpp"
+#include "straus.hpp"
 // Results per lane that share one inversion in the wide fixed-base kernels.  With only 12-16 additions per result
 // the inversion's share is large: measured at 2^24 scalars, batch 16 / 32 / 64: p256 0.96 / 1.03 / 1.06, k256 1.19 /
 // 1.24 / 1.25 x 10^9 per second; p384 (2^22) 282 / 280 / 279 x 10^6 (its results are 144 bytes each in the private
@@ -226,15 +227,64 @@ struct CurveOps {
       hipLaunchKernelGGL((lincomb_ref_kernel<C, 1>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
     } else if (terms == 2) {
       hipLaunchKernelGGL((lincomb_ref_kernel<C, 2>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
-    } else if (terms <= 1024 && !(flags & ECGPU_EXACT_REFERENCE)) {
+    } else if (terms <= 1024 && !(flags & ECGPU_EXACT_REFERENCE) && c->opt[ECGPU_OPT_LINCOMB_TERM_BY_TERM]) {
       hipLaunchKernelGGL((lincomb_sum_kernel<C>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, (int)terms, out, out_fmt, out_inf, n);
+    } else if (terms <= 1024 && !(flags & ECGPU_EXACT_REFERENCE)) {
+      return lincomb_straus(c, sc, pts, pt_fmt, terms, out, out_fmt, out_inf, n);
+    } else if (terms <= 1024 && C::ID == 0) {
+      return lincomb_exact_n(c, sc, pts, pt_fmt, terms, out, out_fmt, out_inf, n);
     } else {
       return ecgpu_set_err(c, ECGPU_ERR_UNSUPPORTED,
-                           "lincomb_batch: more than 2 terms per combination is computed term by term (no exact-XYZ contract, at most 1024 terms; "
-                           "use ecgpu_msm for one large sum)");
+                           "lincomb_batch: at most 1024 terms per combination (use ecgpu_msm for one large sum); ECGPU_EXACT_REFERENCE with more than 2 terms "
+                           "exists for secp256k1 only (the primeorder curves have no in-tree lincomb over slices to be exact to)");
     }
     HIPCHK(c, hipGetLastError());
     return 0;
+  }
+  // the grow-only per-lane workspace of the variable-base kernels
+  static int tab_reserve(ecgpu_ctx* c, size_t need) {
+    if (need <= c->tab_ws_cap) return 0;
+    if (c->tab_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->tab_ws)); c->tab_ws = nullptr; c->tab_ws_cap = 0; }
+    HIPCHK(c, hipMalloc(&c->tab_ws, need));
+    c->tab_ws_cap = need;
+    return 0;
+  }
+  // 3 .. 1024 terms per combination, throughput schedule (straus.hpp): groups of up to 16 terms share the doublings of one window
+  // loop over per-term affine tables; a second small kernel adds the groups' partial sums and writes the outputs
+  static int lincomb_straus(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
+    constexpr int WAVES = 4;
+    int g, gpc;
+    straus::plan(n, terms, resident_lanes(c, WAVES), &g, &gpc);
+    const size_t items = n * (size_t)gpc, upp = (size_t)(straus::SLOTS / g);
+    const unsigned grid = ecgpu_grid_for(c, (items + upp - 1) / upp, WAVES);
+    int rc = tab_reserve(c, (size_t)grid * 256 * sizeof(straus::LaneWs<C>));
+    if (rc) return rc;
+    if ((rc = ecdsa_reserve(c, al256(items * 3 * C::NW * sizeof(u32))))) return rc;
+    u32* partial = (u32*)c->ecdsa_ws;
+    hipLaunchKernelGGL((straus::lincomb_kernel<C, WAVES>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, (int)terms, g, gpc, items,
+                       (straus::LaneWs<C>*)c->tab_ws, partial);
+    hipLaunchKernelGGL((straus::fold_kernel<C>), dim3(ecgpu_grid_for(c, (n + 15) / 16, 8)), dim3(256), 0, c->stream, (const u32*)partial, gpc, out, out_fmt, out_inf, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  // secp256k1 with ECGPU_EXACT_REFERENCE and 3 .. 1024 terms: the reference's interleaved schedule (k256 mul.rs:342-393) with a run-time
+  // term count, tables in a per-lane global scratch; the lane count is capped so that the scratch stays below 8 GB
+  static int lincomb_exact_n(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
+    if constexpr (C::ID != 0) {
+      return ecgpu_set_err(c, ECGPU_ERR_UNSUPPORTED, "exact-reference combinations of more than 2 terms: secp256k1 only");
+    } else {
+      const size_t per_lane = terms * (16 * sizeof(PtK256) + 10 * sizeof(u32));
+      size_t blocks = (n + 255) / 256, cap = (size_t)c->num_cus * ECGPU_REF_WAVES, budget = (((size_t)8 << 30) / (per_lane * 256));
+      if (blocks > cap) blocks = cap;
+      if (blocks > budget) blocks = budget ? budget : 1;
+      const size_t lanes = blocks * 256, sz_tab = al256(lanes * terms * 16 * sizeof(PtK256));
+      int rc = tab_reserve(c, sz_tab + lanes * terms * 10 * sizeof(u32));
+      if (rc) return rc;
+      hipLaunchKernelGGL((k256_lincomb_ref_n_kernel<C>), dim3((unsigned)blocks), dim3(256), 0, c->stream, sc, pts, pt_fmt, (int)terms, out, out_fmt, out_inf, n,
+                         (PtK256*)c->tab_ws, (u32*)((char*)c->tab_ws + sz_tab));
+      HIPCHK(c, hipGetLastError());
+      return 0;
+    }
   }
   static int msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt);
   // resident lanes at `waves` workgroups of 256 per CU (what ecgpu_grid_for caps a grid at)

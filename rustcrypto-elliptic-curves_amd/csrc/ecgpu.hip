@@ -222,6 +222,7 @@ int ecgpu_set_option(ecgpu_ctx* c, int option, int64_t v) {
     case ECGPU_OPT_MSM_ROUNDS: ok = (v >= 0 && v <= 64); break;
     case ECGPU_OPT_K256_WAVES: ok = (v == 3 || v == 4); break;
     case ECGPU_OPT_FB_MEMORY_BUDGET: ok = (v >= 0); break;
+    case ECGPU_OPT_LINCOMB_TERM_BY_TERM: ok = (v == 0 || v == 1); break;
     default: return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_set_option: unknown option %d", option);
   }
   if (!ok) return ecgpu_set_err(c, ECGPU_ERR_ARG, "ecgpu_set_option: value %lld is not allowed for option %d", (long long)v, option);

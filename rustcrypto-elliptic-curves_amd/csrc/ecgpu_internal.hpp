@@ -20,7 +20,7 @@ struct ecgpu_ctx {
   char err[512] = {0};
   std::mutex mu;
   std::mutex err_mu;                          // guards err[] (ecgpu_set_err / ecgpu_last_error_copy)
-  int64_t opt[ECGPU_OPT_COUNT_] = {0, 26, 0, 0, 1, 0, 4, 0};      // ecgpu_option defaults
+  int64_t opt[ECGPU_OPT_COUNT_] = {0, 26, 0, 0, 1, 0, 4, 0, 0};      // ecgpu_option defaults
   // grow-only device staging buffers for ECGPU_MEM_HOST calls: 6 for whole-batch staging, then PIPE_NSLOT pipeline slots x PIPE_MAXARGS arguments
   static constexpr int PIPE_NSLOT = 3, PIPE_MAXARGS = 6, PIPE_STAGE0 = 6;
   static constexpr int NSTAGE = PIPE_STAGE0 + PIPE_NSLOT * PIPE_MAXARGS;

@@ -225,6 +225,32 @@ __global__ void __launch_bounds__(256) lincomb_sum_kernel(const u32* scalars, co
   }
 }
 
+// secp256k1, exact-(X, Y, Z) contract for combinations of any length: the reference's own interleaved schedule (mul_k256.hpp:
+// lincomb_ref_term / lincomb_ref_run) with the per-term tables and digits in a global per-lane scratch (`terms` x (16 points + 10 words)).
+template <class C>
+__global__ void __launch_bounds__(256, ECGPU_REF_WAVES) k256_lincomb_ref_n_kernel(const u32* scalars, const u32* points, int pt_fmt, int terms, u32* out, int out_fmt,
+                                                                                uint8_t* out_inf, size_t n, PtK256* tab_all, u32* dig_all) {
+  static_assert(C::ID == 0, "secp256k1 only");
+  const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  PtK256* tab = tab_all + lane * (size_t)terms * 16;
+  u32* dig = dig_all + lane * (size_t)terms * 10;
+  const int pw = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * C::NW;
+  ECGPU_GRID_STRIDE(i, n) {
+#pragma unroll 1
+    for (int t = 0; t < terms; t++) {
+      u32 k[8];
+      PtK256 p;
+      C::scalar_load(k, scalars + (i * terms + t) * C::NW);
+      load_point<C>(p, points + (i * terms + t) * pw, pt_fmt);
+      k256::lincomb_ref_term(p, k, tab + 16 * t, dig + 10 * t);
+    }
+    PtK256 r;
+    k256::lincomb_ref_run(r, terms, tab, dig);
+    if (out_fmt == FMT_PROJECTIVE) store_projective<C>(out + i * 3 * C::NW, r);
+    else store_affine_from_projective<C>(out + i * 2 * C::NW, out_inf ? out_inf + i : nullptr, r);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k256 variable-base scalar multiplication, throughput schedule (mulfast_k256.hpp).
 // Each lane walks its elements with a grid stride, keeps up to BATCH Jacobian results in its

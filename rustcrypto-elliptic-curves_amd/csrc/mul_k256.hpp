@@ -89,6 +89,47 @@ ECGPU_HD void lincomb_ref(PtK256& acc, const PtK256* pts, const u32 (*ks)[8], Pt
   }
 }
 
+// lincomb (mul.rs:342-393) for a RUN-TIME number of terms (LinearCombinationExt over a slice, mul.rs:325-340): the same steps in the
+// same order, so the (X, Y, Z) that comes out is the reference's; the tables (16 points per term) and the recoded digits (10 words
+// per term) live in scratch the caller provides (global memory: a term's tables are 1.5 KB).
+ECGPU_HD void lincomb_ref_term(const PtK256& p0, const u32* k, PtK256* tab16, u32* dig10) {
+  GlvSplit s;
+  glv_split(s, k);
+  PtK256 p = p0, pb;
+  pt_endomorphism(pb, p);
+  FeK256 ny;
+  neg(ny, p.y);  select(p.y, s.neg1, ny, p.y);       // mul.rs:357-362: conditional_select(x, -x, r1_sign)
+  neg(ny, pb.y); select(pb.y, s.neg2, ny, pb.y);
+  table_build(tab16, p);
+  table_build(tab16 + 8, pb);
+  Radix16<4> d1, d2;
+  radix16_recode<4>(d1, s.k1);
+  radix16_recode<4>(d2, s.k2);
+#pragma unroll
+  for (int q = 0; q < 4; q++) { dig10[q] = d1.y[q]; dig10[4 + q] = d2.y[q]; }
+  dig10[8] = d1.top; dig10[9] = d2.top;
+}
+ECGPU_HD void lincomb_ref_run(PtK256& acc, int terms, const PtK256* tab, const u32* dig) {
+  pt_identity(acc);
+  PtK256 e;
+#pragma unroll 1
+  for (int t = 0; t < terms; t++) {       // mul.rs:370-377: the 33rd digits
+    table_select(e, tab + 16 * t, (int)dig[10 * t + 8]);     pt_add(acc, acc, e);
+    table_select(e, tab + 16 * t + 8, (int)dig[10 * t + 9]); pt_add(acc, acc, e);
+  }
+#pragma unroll 1
+  for (int i = 31; i >= 0; i--) {         // mul.rs:379-391
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) pt_double(acc, acc);
+#pragma unroll 1
+    for (int h = 0; h < 2 * terms; h++) {
+      const u32 w = dig[10 * (h >> 1) + 4 * (h & 1) + (i >> 3)];
+      table_select(e, tab + 8 * h, radix16_digit(w, i & 7));
+      pt_add(acc, acc, e);
+    }
+  }
+}
+
 // `&P * &k` (mul.rs:442-445)
 ECGPU_HD void mul_ref(PtK256& r, const PtK256& p, const u32* k, PtK256* tab) {
   u32 ks[1][8];

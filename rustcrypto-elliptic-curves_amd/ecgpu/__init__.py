@@ -34,7 +34,7 @@ CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384}
 FIELD_BYTES = {K256: 32, P256: 32, P384: 48}
 FE_MUL, FE_SQR, FE_ADD, FE_SUB, FE_NEG, FE_INV, FE_SQRT = range(7)
 # ecgpu_option (per-context tuning / test knobs, include/ecgpu.h)
-OPT_FB_WINDOW, OPT_FB_MAX_WINDOW, OPT_MSM_WINDOW_BITS, OPT_MSM_SLAB_TERMS, OPT_MSM_SMALL_PATH, OPT_MSM_ROUNDS, OPT_K256_WAVES, OPT_FB_MEMORY_BUDGET = range(8)
+OPT_FB_WINDOW, OPT_FB_MAX_WINDOW, OPT_MSM_WINDOW_BITS, OPT_MSM_SLAB_TERMS, OPT_MSM_SMALL_PATH, OPT_MSM_ROUNDS, OPT_K256_WAVES, OPT_FB_MEMORY_BUDGET, OPT_LINCOMB_TERM_BY_TERM = range(9)
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # ECGPU_LIB: another build of the library (A/B measurements of compile-time switches); default: the in-tree build

@@ -54,7 +54,8 @@ pub const ECGPU_OPT_MSM_SMALL_PATH: c_int = 4;
 pub const ECGPU_OPT_MSM_ROUNDS: c_int = 5;
 pub const ECGPU_OPT_K256_WAVES: c_int = 6;
 pub const ECGPU_OPT_FB_MEMORY_BUDGET: c_int = 7;
-pub const ECGPU_OPT_COUNT_: c_int = 8;
+pub const ECGPU_OPT_LINCOMB_TERM_BY_TERM: c_int = 8;
+pub const ECGPU_OPT_COUNT_: c_int = 9;
 /// `ecgpu_group_create` flag: gather the partial sums of a split sum through host memory even where RCCL could be used
 pub const ECGPU_GROUP_NO_RCCL: c_uint = 1;
 

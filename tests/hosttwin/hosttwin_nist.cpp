@@ -269,3 +269,56 @@ extern "C" int ht_mul_ct(int curve, const uint8_t* table_xy, const uint8_t* ks, 
   if (curve == 0) return mul_ct<CurveK256>(table_xy, ks, out, n);
   return curve == 1 ? mul_ct<CurveP256>(table_xy, ks, out, n) : mul_ct<CurveP384>(table_xy, ks, out, n);
 }
+
+// ---- linear combinations of 3 .. 1024 terms (straus.hpp): both stages walked as `lanes` lanes with the product's own plan for
+//      `plan_lanes` resident lanes (g_force > 0 pins the group size instead), and the exact-(X, Y, Z) run-time-N form for secp256k1
+#include "straus.hpp"
+template <class C>
+static int straus_walk(const uint8_t* scalars, const uint8_t* points, int pt_fmt, int terms, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, size_t lanes,
+                       size_t plan_lanes, int g_force, int* g_used) {
+  int g, gpc;
+  straus::plan(n, (size_t)terms, plan_lanes, &g, &gpc);
+  if (g_force > 0) { g = g_force; gpc = (terms + g - 1) / g; }
+  if (g_used) { g_used[0] = g; g_used[1] = gpc; }
+  const size_t items = n * (size_t)gpc, upp = (size_t)(straus::SLOTS / g);
+  straus::LaneWs<C>* ws = (straus::LaneWs<C>*)malloc(sizeof(straus::LaneWs<C>));
+  u32* partial = (u32*)malloc(items * 3 * C::NW * sizeof(u32));
+  memset(ws, 0xA5, sizeof(*ws));
+  for (size_t tid = 0; tid < lanes; tid++)
+    for (size_t base = tid; base < items; base += lanes * upp)
+      straus::lane_pass<C>((const u32*)scalars, (const u32*)points, pt_fmt, terms, g, gpc, items, base, lanes, *ws, partial);
+  for (size_t tid = 0; tid < lanes; tid++)
+    for (size_t base = tid; base < n; base += lanes * 16)
+      straus::fold_pass<C, 16>(partial, gpc, (u32*)out, out_fmt, out_inf, n, base, lanes);
+  free(partial);
+  free(ws);
+  return 0;
+}
+extern "C" int ht_straus(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, int terms, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
+                         size_t lanes, size_t plan_lanes, int g_force, int* g_used) {
+  if (curve == 0) return straus_walk<CurveK256>(scalars, points, pt_fmt, terms, out, out_fmt, out_inf, n, lanes, plan_lanes, g_force, g_used);
+  return curve == 1 ? straus_walk<CurveP256>(scalars, points, pt_fmt, terms, out, out_fmt, out_inf, n, lanes, plan_lanes, g_force, g_used)
+                    : straus_walk<CurveP384>(scalars, points, pt_fmt, terms, out, out_fmt, out_inf, n, lanes, plan_lanes, g_force, g_used);
+}
+// secp256k1 lincomb_ext over a slice, exact (X, Y, Z): points X || Y || Z in, X || Y || Z out
+extern "C" int ht_k256_lincomb_ref_n(const uint8_t* scalars, const uint8_t* points_xyz, int terms, uint8_t* out_xyz, size_t n) {
+  using C = CurveK256;
+  PtK256* tab = (PtK256*)malloc(sizeof(PtK256) * 16 * (size_t)terms);
+  u32* dig = (u32*)malloc(sizeof(u32) * 10 * (size_t)terms);
+  for (size_t i = 0; i < n; i++) {
+    for (int t = 0; t < terms; t++) {
+      PtK256 p;
+      load_pt<C>(p, points_xyz + 96 * (i * terms + t));
+      u32 w[8], k[8];
+      memcpy(w, scalars + 32 * (i * terms + t), 32);
+      C::scalar_load(k, w);
+      k256::lincomb_ref_term(p, k, tab + 16 * t, dig + 10 * t);
+    }
+    PtK256 r;
+    k256::lincomb_ref_run(r, terms, tab, dig);
+    store_pt<C>(out_xyz + 96 * i, r);
+  }
+  free(tab);
+  free(dig);
+  return 0;
+}

@@ -498,3 +498,29 @@ def test_sec1_uncompressed_and_compressed_records(cn, cid, ref_vectors):
     assert ctx.lib.ecgpu_sec1_decode_batch(ctx.handle, cid, ctypes.c_void_p(bad.ctypes.data), 17, ctypes.c_void_p(out.ctypes.data),
                                            ctypes.c_void_p(ok.ctypes.data), 8, ecgpu.HOST) == -1
     ctx.close()
+
+
+def test_memory_budget_never_refuses_the_mandatory_tables():
+    """ECGPU_OPT_FB_MEMORY_BUDGET is documented as a knob "never needed for correct results", yet a budget below the
+    5-bit table of the constant-time fixed-base kernel made signing and SECRET_SCALARS key generation fail with an out-of-memory
+    error.  The budget is about the optional wide tables: with a budget of one byte signing, key generation and the public-data
+    generator multiplication (on the 8-bit base table) all work and agree with an unbudgeted context."""
+    import ecgpu
+    ctx, ref = ecgpu.Context(0), ecgpu.Context(0)
+    ctx.set_option(ecgpu.OPT_FB_MEMORY_BUDGET, 1)
+    for cn, cid in (("k256", 0), ("p384", 2)):
+        cv, rv = ctx.curve(cn), ref.curve(cn)
+        n = 300_000                                   # the size rule would pick the 16-bit table
+        d = CO.synth_scalars(cid, n, synth.SEED, 77)
+        k = CO.synth_scalars(cid, n, synth.SEED + 1, 77)
+        z = CO.synth_scalars(cid, n, synth.SEED + 2, 77)
+        sig, rec, ok = cv.ecdsa_sign(d[:5000], k[:5000], z[:5000])
+        sig2, rec2, ok2 = rv.ecdsa_sign(d[:5000], k[:5000], z[:5000])
+        assert ok.all() and bytes(sig) == bytes(sig2) and bytes(rec) == bytes(rec2)
+        keys, _ = cv.mul_by_generator(d[:5000], flags=ecgpu.SECRET_SCALARS)
+        pub, _ = cv.mul_by_generator(d)
+        pub2, _ = rv.mul_by_generator(d)
+        assert bytes(pub) == bytes(pub2) and bytes(keys) == bytes(pub[:5000])
+        assert ctx.fb_table_bytes(cn)[1] == 8 and ref.fb_table_bytes(cn)[1] == 16
+    ctx.close()
+    ref.close()

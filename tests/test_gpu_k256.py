@@ -270,8 +270,90 @@ def test_lincomb_many_terms(cn):
                 assert inf[i] == 1 and not bytes(out[i]).strip(b"\0")
             else:
                 assert inf[i] == 0 and bytes(out[i]) == M.i2b(c, acc[0]) + M.i2b(c, acc[1]), (terms, i)
-    with pytest.raises(ecgpu.EcgpuError):
-        cv.lincomb(sb, pb, terms=16, flags=ecgpu.EXACT_REFERENCE)
+        # the term-by-term form of rounds 1-3 (one reference multiplication per term) is an independent path to the same bytes
+        ctx.set_option(ecgpu.OPT_LINCOMB_TERM_BY_TERM, 1)
+        out2, inf2 = cv.lincomb(sb, pb, terms=terms)
+        ctx.set_option(ecgpu.OPT_LINCOMB_TERM_BY_TERM, 0)
+        assert bytes(out2) == bytes(out) and bytes(inf2) == bytes(inf)
+    if cn == "k256":
+        xyz = cv.lincomb(sb, pb, terms=16, out_format=ecgpu.PROJECTIVE, flags=ecgpu.EXACT_REFERENCE)
+        for i in (0, 1, 2, 7):
+            want = M.k256_lincomb_ref([((P[0], P[1], 1) if P is not None else M.IDENTITY, k) for k, P in zip(ks[i], ps[i])])
+            assert bytes(xyz[i]) == M.proj_bytes(c, want), i
+    else:
+        with pytest.raises(ecgpu.EcgpuError):
+            cv.lincomb(sb, pb, terms=16, flags=ecgpu.EXACT_REFERENCE)
+    ctx.close()
+
+
+@pytest.mark.parametrize("terms", [3, 5, 16])
+def test_k256_lincomb_ext_exact_xyz(terms):
+    """LinearCombinationExt over a slice (k256 mul.rs:325-340) with ECGPU_EXACT_REFERENCE: the reference's interleaved schedule for a
+    run-time number of terms returns the very (X, Y, Z) of the model's restatement of mul.rs:342-393 - projective inputs (Z != 1),
+    identities, zero scalars, cancelling terms; 300 combinations so that several lanes and the grid stride take part."""
+    import random
+    import ecgpu
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve("k256")
+    c = M.K256
+    rng = random.Random(900 + terms)
+    n = 300
+    base = [M.affine_mul(c, rng.randrange(1, c.n), (c.gx, c.gy)) for _ in range(9)]
+    ks, pts = [], []
+    for i in range(n * terms):
+        ks.append(rng.randrange(c.n))
+        P = base[rng.randrange(9)]
+        z = rng.randrange(1, c.p)
+        pts.append((P[0] * z % c.p, P[1] * z % c.p, z))
+    ks[0] = 0
+    pts[1] = M.IDENTITY
+    pts[terms + 1], ks[terms + 1] = pts[terms], (c.n - ks[terms]) % c.n
+    sb = b"".join(k.to_bytes(32, "big") for k in ks)
+    pb = b"".join(M.proj_bytes(c, P) for P in pts)
+    xyz = cv.lincomb(sb, pb, terms=terms, point_format=ecgpu.PROJECTIVE, out_format=ecgpu.PROJECTIVE, flags=ecgpu.EXACT_REFERENCE)
+    for i in list(range(6)) + [n // 2, n - 1]:
+        want = M.k256_lincomb_ref(list(zip(pts[i * terms:(i + 1) * terms], ks[i * terms:(i + 1) * terms])))
+        assert bytes(xyz[i]) == M.proj_bytes(c, want), (terms, i)
+    # the affine form of the same call equals the throughput schedule's bytes
+    a1, i1 = cv.lincomb(sb, pb, terms=terms, point_format=ecgpu.PROJECTIVE, flags=ecgpu.EXACT_REFERENCE)
+    a2, i2 = cv.lincomb(sb, pb, terms=terms, point_format=ecgpu.PROJECTIVE)
+    assert bytes(a1) == bytes(a2) and bytes(i1) == bytes(i2)
+    ctx.close()
+
+
+@pytest.mark.parametrize("cn", ["k256", "p256", "p384"])
+@pytest.mark.parametrize("terms,n", [(1024, 3), (100, 40), (17, 5000), (7, 70001)])
+def test_lincomb_many_terms_shapes(cn, terms, n):
+    """Shapes of the shared-doubling schedule (csrc/straus.hpp): 1024 terms (the maximum: groups of 4 per work item on an idle chip),
+    100 and 17 terms (several balanced groups per combination, the second stage adds them), 7 terms x 70 001 (two combinations per
+    pass, ragged) - against the term-by-term path on all combinations and the C oracle on a sample."""
+    import ecgpu
+    from oracle import coracle as CO
+    from oracle import synth
+    ctx = ecgpu.Context(0)
+    cv = ctx.curve(cn)
+    cid = cv.id
+    nb = cv.nb
+    if cid == 2 and terms * n > 200000:
+        n = 200000 // terms
+    s = CO.synth_scalars(cid, n * terms, synth.SEED, 61_000_000)
+    p = CO.synth_points(cid, n * terms, synth.SEED, 61_000_000)
+    s[3] = 0
+    p[terms + 2] = 0
+    out, inf = cv.lincomb(s, p, terms=terms)
+    ctx.set_option(ecgpu.OPT_LINCOMB_TERM_BY_TERM, 1)
+    out2, inf2 = cv.lincomb(s, p, terms=terms)
+    ctx.set_option(ecgpu.OPT_LINCOMB_TERM_BY_TERM, 0)
+    assert bytes(out) == bytes(out2) and bytes(inf) == bytes(inf2)
+    for i in (0, 1, n - 1):                       # the oracle: term-by-term products summed with the model's affine addition
+        c = M.CURVES[cn]
+        prod = CO.lincomb_batch(cid, s[i * terms:(i + 1) * terms], p[i * terms:(i + 1) * terms], threads=8)
+        acc = None
+        for r in prod:
+            if r[-1]:
+                continue
+            acc = M.affine_add(c, acc, (int.from_bytes(bytes(r[:nb]), "big"), int.from_bytes(bytes(r[nb:2 * nb]), "big")))
+        assert bytes(out[i]) == M.i2b(c, acc[0]) + M.i2b(c, acc[1]) and inf[i] == 0, (terms, i)
     ctx.close()
 
 
