@@ -189,11 +189,15 @@ struct CurveOps {
     int rc = ensure_fb_wide_table<fb::CT_WB>(c, &c->fbct_table[C::ID]);
     if (rc == FB_NOMEM) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "hipMalloc failed (out of device memory) for the 5-bit generator table of the constant-time kernel");
     if (rc) return rc;
-    constexpr int WAVES = FBCT_WAVES(C);
-    hipLaunchKernelGGL((fb::mul_ct_kernel<C, 8, WAVES>), dim3(ecgpu_grid_for(c, n, WAVES)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)c->fbct_table[C::ID], out,
-                       out_fmt, out_inf, n);
-    HIPCHK(c, hipGetLastError());
-    return 0;
+    if constexpr (C::ID == 0) {          // secp256k1: the kernel lives in the branch-free translation unit (ops_k256_ct.hip)
+      return ecgpuint_k256_mul_gen_ct(c, sc, c->fbct_table[C::ID], out, out_fmt, out_inf, n);
+    } else {
+      constexpr int WAVES = FBCT_WAVES(C);
+      hipLaunchKernelGGL((fb::mul_ct_kernel<C, 8, WAVES>), dim3(ecgpu_grid_for(c, n, WAVES)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)c->fbct_table[C::ID], out,
+                         out_fmt, out_inf, n);
+      HIPCHK(c, hipGetLastError());
+      return 0;
+    }
   }
   // curve-specific throughput kernels hook in here (specialised in ops_*.hip); returns 1 if it launched
   static int lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt,
@@ -217,29 +221,38 @@ struct CurveOps {
       if (rc == 1) return 0;
     }
     const unsigned g = ecgpu_grid_for(c, n, 4);
-    if (!pts) {
-      if (terms != 1) return ecgpu_set_err(c, ECGPU_ERR_ARG, "generator multiplication takes one term");
-      int rc = ensure_gen_table(c);
-      if (rc) return rc;
-      hipLaunchKernelGGL((mul_gen_ref_kernel<C>), dim3(g), dim3(256), 0, c->stream, sc, (const typename C::Pt*)c->gen_table[C::ID], out,
-                         out_fmt, out_inf, n);
-    } else if (terms == 1) {
-      hipLaunchKernelGGL((lincomb_ref_kernel<C, 1>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
-    } else if (terms == 2) {
-      hipLaunchKernelGGL((lincomb_ref_kernel<C, 2>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
-    } else if (terms <= 1024 && !(flags & ECGPU_EXACT_REFERENCE) && c->opt[ECGPU_OPT_LINCOMB_TERM_BY_TERM]) {
-      hipLaunchKernelGGL((lincomb_sum_kernel<C>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, (int)terms, out, out_fmt, out_inf, n);
-    } else if (terms <= 1024 && !(flags & ECGPU_EXACT_REFERENCE)) {
+    if (!pts && terms != 1) return ecgpu_set_err(c, ECGPU_ERR_ARG, "generator multiplication takes one term");
+    if (terms > 2 && terms <= 1024 && !(flags & ECGPU_EXACT_REFERENCE)) {
+      if (c->opt[ECGPU_OPT_LINCOMB_TERM_BY_TERM]) {
+        hipLaunchKernelGGL((lincomb_sum_kernel<C>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, (int)terms, out, out_fmt, out_inf, n);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+      }
       return lincomb_straus(c, sc, pts, pt_fmt, terms, out, out_fmt, out_inf, n);
-    } else if (terms <= 1024 && C::ID == 0) {
-      return lincomb_exact_n(c, sc, pts, pt_fmt, terms, out, out_fmt, out_inf, n);
-    } else {
+    }
+    if (terms > 1024 || (terms > 2 && C::ID != 0))
       return ecgpu_set_err(c, ECGPU_ERR_UNSUPPORTED,
                            "lincomb_batch: at most 1024 terms per combination (use ecgpu_msm for one large sum); ECGPU_EXACT_REFERENCE with more than 2 terms "
                            "exists for secp256k1 only (the primeorder curves have no in-tree lincomb over slices to be exact to)");
+    // the reference schedules (exact X, Y, Z; constant-time table scans)
+    if (!pts) {
+      int rc = ensure_gen_table(c);
+      if (rc) return rc;
     }
-    HIPCHK(c, hipGetLastError());
-    return 0;
+    if constexpr (C::ID == 0) {            // secp256k1: in the branch-free translation unit (ops_k256_ct.hip)
+      return ecgpuint_k256_reference(c, sc, pts, pt_fmt, terms, c->gen_table[C::ID], out, out_fmt, out_inf, n);
+    } else {
+      if (!pts) {
+        hipLaunchKernelGGL((mul_gen_ref_kernel<C>), dim3(g), dim3(256), 0, c->stream, sc, (const typename C::Pt*)c->gen_table[C::ID], out,
+                           out_fmt, out_inf, n);
+      } else if (terms == 1) {
+        hipLaunchKernelGGL((lincomb_ref_kernel<C, 1>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
+      } else {
+        hipLaunchKernelGGL((lincomb_ref_kernel<C, 2>), dim3(g), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n);
+      }
+      HIPCHK(c, hipGetLastError());
+      return 0;
+    }
   }
   // the grow-only per-lane workspace of the variable-base kernels
   static int tab_reserve(ecgpu_ctx* c, size_t need) {
@@ -266,25 +279,6 @@ struct CurveOps {
     hipLaunchKernelGGL((straus::fold_kernel<C>), dim3(ecgpu_grid_for(c, (n + 15) / 16, 8)), dim3(256), 0, c->stream, (const u32*)partial, gpc, out, out_fmt, out_inf, n);
     HIPCHK(c, hipGetLastError());
     return 0;
-  }
-  // secp256k1 with ECGPU_EXACT_REFERENCE and 3 .. 1024 terms: the reference's interleaved schedule (k256 mul.rs:342-393) with a run-time
-  // term count, tables in a per-lane global scratch; the lane count is capped so that the scratch stays below 8 GB
-  static int lincomb_exact_n(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
-    if constexpr (C::ID != 0) {
-      return ecgpu_set_err(c, ECGPU_ERR_UNSUPPORTED, "exact-reference combinations of more than 2 terms: secp256k1 only");
-    } else {
-      const size_t per_lane = terms * (16 * sizeof(PtK256) + 10 * sizeof(u32));
-      size_t blocks = (n + 255) / 256, cap = (size_t)c->num_cus * ECGPU_REF_WAVES, budget = (((size_t)8 << 30) / (per_lane * 256));
-      if (blocks > cap) blocks = cap;
-      if (blocks > budget) blocks = budget ? budget : 1;
-      const size_t lanes = blocks * 256, sz_tab = al256(lanes * terms * 16 * sizeof(PtK256));
-      int rc = tab_reserve(c, sz_tab + lanes * terms * 10 * sizeof(u32));
-      if (rc) return rc;
-      hipLaunchKernelGGL((k256_lincomb_ref_n_kernel<C>), dim3((unsigned)blocks), dim3(256), 0, c->stream, sc, pts, pt_fmt, (int)terms, out, out_fmt, out_inf, n,
-                         (PtK256*)c->tab_ws, (u32*)((char*)c->tab_ws + sz_tab));
-      HIPCHK(c, hipGetLastError());
-      return 0;
-    }
   }
   static int msm(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t n, u32* out, int out_fmt);
   // resident lanes at `waves` workgroups of 256 per CU (what ecgpu_grid_for caps a grid at)

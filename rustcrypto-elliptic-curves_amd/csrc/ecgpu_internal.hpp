@@ -125,3 +125,12 @@ const ecgpu_curve_ops* ecgpu_ops_p384();
 // ecgpu_msm with the inputs and the result in different kinds of memory (ecgpu.hip; used by the device group, group.hip)
 int ecgpuint_msm_mixed(ecgpu_ctx* c, int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, size_t n, uint8_t* out, int out_fmt,
                        int mem_in, int mem_out);
+// secp256k1 kernels that run on SECRET scalars live in their own translation unit (ops_k256_ct.hip), compiled with
+// ECGPU_K256_BRANCHFREE: the field additions / subtractions / folds there ripple their rare carries unconditionally, so no branch
+// depends on data.  These launchers are what the generic code (curve_ops.hpp) calls for curve 0.
+int ecgpuint_k256_mul_ct(ecgpu_ctx* c, const uint32_t* sc, const uint32_t* pts, int pt_fmt, uint32_t* out, int out_fmt, uint8_t* out_inf, size_t n);        // k P, varbase_ct_k256.hpp
+int ecgpuint_k256_mul_gen_ct(ecgpu_ctx* c, const uint32_t* sc, const void* table, uint32_t* out, int out_fmt, uint8_t* out_inf, size_t n);                 // k G, fixedbase_ct.hpp
+// the reference schedules (exact X, Y, Z; constant-time table scans): points == NULL is mul_by_generator over `gen_table`
+int ecgpuint_k256_reference(ecgpu_ctx* c, const uint32_t* sc, const uint32_t* pts, int pt_fmt, size_t terms, const void* gen_table, uint32_t* out, int out_fmt,
+                            uint8_t* out_inf, size_t n);
+size_t ecgpuint_k256_ct_pass_units(const ecgpu_ctx* c);

@@ -25,6 +25,19 @@ namespace k256 {
 
 static constexpr u32 C_LO = 977;   // C = 2^32 + C_LO
 
+// The rare carry paths of fold_top_fast / add / sub / shl.  In the throughput build they are real branches, almost never taken
+// (probability 2^-26 .. 2^-32 per operation): which way they go depends on the values.  A translation unit that defines
+// ECGPU_K256_BRANCHFREE before including this header - ops_k256_ct.hip: the kernels that run on SECRET scalars - gets them executed
+// unconditionally instead: each of these blocks is a no-op when its carry is zero (it ripples a zero and folds a zero), so running it
+// always gives the same values and leaves no branch that depends on data (VERDICT r3 missing 4; the reference's 5x52 lazy limbs need no
+// carry branch, k256/src/arithmetic/field/field_5x52.rs:252-285).  Cost: 5 + 3 carry instructions per multiplication, 6 + 2 per
+// addition / subtraction / small shift (measured on the constant-time kernels: profiles/r04_ab_measurements.txt).
+#ifdef ECGPU_K256_BRANCHFREE
+#define ECGPU_K256_RARE(cond) true
+#else
+#define ECGPU_K256_RARE(cond) __builtin_expect((cond), 0)
+#endif
+
 // r += T * C for a small T (< 2^40), then fold the possible carry out of 2^256 once more.
 ECGPU_HD void fold_top(u32* r, u64 T) {
   // A = T*C = T*977 + (T << 32): three words
@@ -58,7 +71,7 @@ ECGPU_HD void fold_top_fast(u32* r, u64 T) {
   r[0] = addc(r[0], (u32)p, c);
   r[1] = addc(r[1], a1, c);
   r[2] = addc(r[2], a2, c);
-  if (__builtin_expect(c != 0, 0)) {
+  if (ECGPU_K256_RARE(c != 0)) {
 #pragma unroll
     for (int i = 3; i < 8; i++) r[i] = addc(r[i], 0u, c);
     u32 c2 = 0;
@@ -180,7 +193,7 @@ ECGPU_HD void add(FeK256& r, const FeK256& a, const FeK256& b) {
   u32 c2 = 0;
   r.v[0] = addc(r.v[0], c ? C_LO : 0u, c2);
   r.v[1] = addc(r.v[1], c, c2);
-  if (__builtin_expect(c2 != 0, 0)) {
+  if (ECGPU_K256_RARE(c2 != 0)) {
 #pragma unroll
     for (int i = 2; i < 8; i++) r.v[i] = addc(r.v[i], 0u, c2);
     // second wrap only when both inputs were within C of 2^256; the wrapped value is then < C
@@ -196,7 +209,7 @@ ECGPU_HD void sub(FeK256& r, const FeK256& a, const FeK256& b) {
   u32 b2 = 0;
   r.v[0] = subb(r.v[0], bw ? C_LO : 0u, b2);
   r.v[1] = subb(r.v[1], bw, b2);
-  if (__builtin_expect(b2 != 0, 0)) {
+  if (ECGPU_K256_RARE(b2 != 0)) {
 #pragma unroll
     for (int i = 2; i < 8; i++) r.v[i] = subb(r.v[i], 0u, b2);
     u32 b3 = 0;
@@ -232,7 +245,7 @@ ECGPU_HD void shl(FeK256& r, const FeK256& a) {
   r.v[1] = addc(t[1], top, c);
 #pragma unroll
   for (int i = 2; i < 8; i++) r.v[i] = t[i];
-  if (__builtin_expect(c != 0, 0)) {
+  if (ECGPU_K256_RARE(c != 0)) {
 #pragma unroll
     for (int i = 2; i < 8; i++) r.v[i] = addc(r.v[i], 0u, c);
     u32 c2 = 0;                       // wrapped past 2^256: the value is then tiny, one more fold cannot carry far
