@@ -84,9 +84,13 @@ enum {
   /* The reference schedule is also its constant-time one: table entries are picked by the reference's masked scan over
    * the whole table (k256 mul.rs:92-127, primeorder projective.rs:132-137), formulas are complete, and nothing - no
    * branch, no address - depends on a digit of the scalar.  It is the schedule to use for secret scalars (ECDH, signing
-   * nonces); staged host copies of the scalars are cleared before the call returns.  One caveat, stated rather than
-   * hidden: the field additions and the final fold of a multiplication take a rare carry path (probability ~2^-26 to
-   * 2^-32 per operation on uniformly distributed values) as a real branch, where the reference's 5x52 limbs need none.
+   * nonces); staged host copies of the scalars are cleared before the call returns.  The field arithmetic under the kernels
+   * that run on secret scalars has no data-dependent branch either: the Montgomery fields of P-256 / P-384 never had one, and the
+   * secp256k1 kernels of this kind are compiled in their own translation unit in which the rare carry paths of the saturated-limb
+   * additions, subtractions and folds (probability 2^-26 .. 2^-32 per operation; real branches in the throughput kernels) execute
+   * unconditionally (csrc/ops_k256_ct.hip; branch listing and counters: profiles/r04_k256_ct_branches.txt; cost 5-10 %).
+   * What remains outside the claim: the scalar-field arithmetic of ecgpu_ecdsa_sign_batch's last step (s = k^-1 (z + r d) mod n) is
+   * masked but not audited instruction by instruction, and GPU hardware gives no timing guarantees of its own.
    * The throughput schedules (default for ecgpu_mul_batch / ecgpu_lincomb_batch / ecgpu_msm) skip zero digits, index
    * tables by digits and branch on exceptional cases: bulk PUBLIC data only. */
   ECGPU_EXACT_REFERENCE = 1u,

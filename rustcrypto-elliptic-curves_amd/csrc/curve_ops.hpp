@@ -16,6 +16,10 @@
 #ifndef FB_BATCH
 #define FB_BATCH (C::NW > 8 ? 16 : 64)
 #endif
+// occupancy target of the wide fixed-base kernel (A/B switch: 3 = 168 VGPRs, room for the gather prefetch ECGPU_FB_PREFETCH)
+#ifndef FB_WIDE_WAVES
+#define FB_WIDE_WAVES 4
+#endif
 
 // occupancy target (waves per SIMD) of the constant-time fixed-base kernel fb::mul_ct_kernel.  With the Jacobian addition (fixedbase_ct.hpp)
 // the live set fits 128 VGPRs on the 8-word curves (k256: 10 spilled) and 168 on P-384 (15 spilled); signing per 2^20 at these against the
@@ -150,8 +154,8 @@ struct CurveOps {
   static int mul_gen_wide(ecgpu_ctx* c, void** slot, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
     int rc = ensure_fb_wide_table<WB>(c, slot);
     if (rc) return rc;
-    hipLaunchKernelGGL((fb::mul_wide_kernel<C, WB, FB_BATCH, 4>), dim3(ecgpu_grid_for(c, n, 4)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)*slot, out, out_fmt,
-                       out_inf, n);
+    hipLaunchKernelGGL((fb::mul_wide_kernel<C, WB, FB_BATCH, FB_WIDE_WAVES>), dim3(ecgpu_grid_for(c, n, FB_WIDE_WAVES)), dim3(256), 0, c->stream, sc,
+                       (const AffEntry<C>*)*slot, out, out_fmt, out_inf, n);
     HIPCHK(c, hipGetLastError());
     return 1;
   }

@@ -277,9 +277,8 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
       FbAcc<C>::set_infinity(acc);
       int filled = 0;                                     // 0: empty, 1: one entry (affine: Z = 1 / ZZ = ZZZ = 1), 2: a sum
       u32 carry = 0;
-#pragma unroll 1
-      for (int j = 0; j < nwin_wide<C, WB>(); j++) {
-        // WB bits of k from bit WB j (words beyond the scalar read as zero)
+      // signed digit of window j (WB bits of k from bit WB j, words beyond the scalar read as zero; updates the recoding carry)
+      auto digit = [&](int j) -> int {
         const int wi = (WB * j) >> 5, sh = (WB * j) & 31;
         u32 w0 = 0, w1 = 0;
 #pragma unroll
@@ -287,7 +286,32 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
         const u64 pair = ((u64)w1 << 32) | w0;
         u32 d = ((u32)(pair >> sh) & ((1u << WB) - 1u)) + carry;
         carry = (d >= (1u << (WB - 1))) ? 1u : 0u;      // d in [2^(WB-1), 2^WB] becomes d - 2^WB with a carry
-        const int sd = (int)d - (int)(carry << WB);
+        return (int)d - (int)(carry << WB);
+      };
+#ifdef ECGPU_FB_PREFETCH
+      // A/B switch (round 4): software pipeline over the gathers - the entry of window j + 1 is in flight during
+      // the addition of window j (16 / 24 more live registers: meant for WAVES = 3)
+      int nsd = digit(0);
+      typename C::Fe nx, ny;
+      if (nsd != 0) { const AffEntry<C>* e = table + ((nsd < 0 ? -nsd : nsd) - 1); nx = e->x; ny = e->y; }
+#pragma unroll 1
+      for (int j = 0; j < nwin_wide<C, WB>(); j++) {
+        const int sd = nsd;
+        typename C::Fe x = nx, y = ny;
+        if (j + 1 < nwin_wide<C, WB>()) {
+          nsd = digit(j + 1);
+          if (nsd != 0) { const AffEntry<C>* e = table + (size_t)(j + 1) * wide_entries<WB>() + ((nsd < 0 ? -nsd : nsd) - 1); nx = e->x; ny = e->y; }
+        }
+        if (sd != 0) {
+          if ((sd < 0) != flip) C::fe_neg(y, y);
+          if (filled == 1) { FbAcc<C>::add_affine(acc, x, y); filled = 2; }
+          else { FbAcc<C>::add_mixed(acc, x, y); filled = filled ? 2 : 1; }
+        }
+      }
+#else
+#pragma unroll 1
+      for (int j = 0; j < nwin_wide<C, WB>(); j++) {
+        const int sd = digit(j);
         if (sd != 0) {
           const AffEntry<C>* e = table + (size_t)j * wide_entries<WB>() + ((sd < 0 ? -sd : sd) - 1);
           typename C::Fe x = e->x, y = e->y;
@@ -298,6 +322,7 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
           else { FbAcc<C>::add_mixed(acc, x, y); filled = filled ? 2 : 1; }
         }
       }
+#endif
       res[b] = acc;
       cnt = b + 1;
     }

@@ -578,6 +578,10 @@ template <class C, int CB>
 __device__ __forceinline__ RawPoint<C> entry_point(const u32* prep, size_t n, u32 e) {
 #ifdef MSM_HOT_GATHER
   const uint4* src = (const uint4*)(prep + ((size_t)((e >> 30) & 1u) * n + (e & (u32)MSM_HOT_GATHER)) * 2 * C::NW);
+#elif defined(MSM_DIAG_ONE_ARRAY)
+  // DIAGNOSTIC ONLY (wrong sums, round 4): both GLV halves gather from half 0's array - what halving the gathers' footprint
+  // (1 GB -> 512 MB at 2^23 terms) would buy at most, before the sort is made half-aware to do it for real
+  const uint4* src = (const uint4*)(prep + (size_t)(e & Geo<CB>::INDEX_MASK) * 2 * C::NW);
 #else
   const uint4* src = (const uint4*)(prep + ((size_t)((e >> 30) & 1u) * n + (e & Geo<CB>::INDEX_MASK)) * 2 * C::NW);
 #endif

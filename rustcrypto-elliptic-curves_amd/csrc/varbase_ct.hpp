@@ -30,7 +30,7 @@
 // P to jP, j = 2 .. 7: exceptional only if (j -+ 1) P = O, impossible for prime n > 8.  An identity INPUT is
 // replaced by G under a mask and the result forced to the identity.  Inputs that are not on the curve give unspecified
 // output, as they would violate the reference's type invariants; the instruction stream does not depend on them either.
-// The caveat of every schedule in this library applies: field additions take a rare carry path as a real branch.
+// (The Montgomery field of these curves, fe_mont.hpp, has no carry branch: additions and subtractions end in a masked correction.)
 #pragma once
 #include "jacobian.hpp"
 

@@ -39,7 +39,7 @@
 // ecgpu_ecdh_batch rejects them before this kernel); the instruction stream does not depend on them.
 // Round 3 first shipped this kernel on the complete formulas (the argument above was thought not to carry over from the fold
 // of varbase_ct.hpp; it does, with the bounds made explicit): 8.8 x 10^7 /s then, 1.06 x 10^8 /s now.
-// The caveat of every schedule here applies: the field additions' rare carry path is a branch.
+// The kernel is instantiated in ops_k256_ct.hip, where the field additions' rare carry paths run unconditionally (fe_k256.hpp ECGPU_K256_RARE): no branch depends on data.
 #pragma once
 #include "varbase_ct.hpp"
 #include "mulfast_k256.hpp"
