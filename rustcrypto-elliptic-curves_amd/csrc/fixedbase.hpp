@@ -288,41 +288,49 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
         carry = (d >= (1u << (WB - 1))) ? 1u : 0u;      // d in [2^(WB-1), 2^WB] becomes d - 2^WB with a carry
         return (int)d - (int)(carry << WB);
       };
-#ifdef ECGPU_FB_PREFETCH
-      // A/B switch (round 4): software pipeline over the gathers - the entry of window j + 1 is in flight during
-      // the addition of window j (16 / 24 more live registers: meant for WAVES = 3)
-      int nsd = digit(0);
-      typename C::Fe nx, ny;
-      if (nsd != 0) { const AffEntry<C>* e = table + ((nsd < 0 ? -nsd : nsd) - 1); nx = e->x; ny = e->y; }
-#pragma unroll 1
-      for (int j = 0; j < nwin_wide<C, WB>(); j++) {
-        const int sd = nsd;
-        typename C::Fe x = nx, y = ny;
-        if (j + 1 < nwin_wide<C, WB>()) {
-          nsd = digit(j + 1);
-          if (nsd != 0) { const AffEntry<C>* e = table + (size_t)(j + 1) * wide_entries<WB>() + ((nsd < 0 ? -nsd : nsd) - 1); nx = e->x; ny = e->y; }
-        }
-        if (sd != 0) {
-          if ((sd < 0) != flip) C::fe_neg(y, y);
-          if (filled == 1) { FbAcc<C>::add_affine(acc, x, y); filled = 2; }
-          else { FbAcc<C>::add_mixed(acc, x, y); filled = filled ? 2 : 1; }
-        }
-      }
+      // Software pipeline over the gathers (round 4): the entry of window j + 1 is in flight during the addition of window j.  16 more
+      // live registers (128 VGPRs, 7 spilled on P-256); p256 fixed base 2^24: 12.48-12.59 ms against 12.65-12.76 (-1.6 %, three alternating
+      // passes, profiles/r04_ab_measurements.txt); at 3 waves per SIMD with or without it: 13.0-13.3 ms.  P-384's 24 extra registers cost
+      // it 18 % (round 2): the plain loop stays there.  ECGPU_FB_NO_PREFETCH: A/B switch.
+#ifdef ECGPU_FB_NO_PREFETCH
+      constexpr bool PREFETCH = false;
 #else
+      constexpr bool PREFETCH = (NW <= 8);
+#endif
+      if constexpr (PREFETCH) {
+        int nsd = digit(0);
+        typename C::Fe nx, ny;
+        C::fe_zero(nx); C::fe_zero(ny);
+        if (nsd != 0) { const AffEntry<C>* e = table + ((nsd < 0 ? -nsd : nsd) - 1); nx = e->x; ny = e->y; }
 #pragma unroll 1
-      for (int j = 0; j < nwin_wide<C, WB>(); j++) {
-        const int sd = digit(j);
-        if (sd != 0) {
-          const AffEntry<C>* e = table + (size_t)j * wide_entries<WB>() + ((sd < 0 ? -sd : sd) - 1);
-          typename C::Fe x = e->x, y = e->y;
-          if ((sd < 0) != flip) C::fe_neg(y, y);
-          // the second entry meets an accumulator with ZZ = ZZZ = 1: 4M + 2S instead of 8M + 2S (one of the nine additions of a
-          // 26-bit-window multiplication; the lanes of a wave disagree about `filled` only after a zero digit, 2^-WB per window)
-          if (filled == 1) { FbAcc<C>::add_affine(acc, x, y); filled = 2; }
-          else { FbAcc<C>::add_mixed(acc, x, y); filled = filled ? 2 : 1; }
+        for (int j = 0; j < nwin_wide<C, WB>(); j++) {
+          const int sd = nsd;
+          typename C::Fe x = nx, y = ny;
+          if (j + 1 < nwin_wide<C, WB>()) {
+            nsd = digit(j + 1);
+            if (nsd != 0) { const AffEntry<C>* e = table + (size_t)(j + 1) * wide_entries<WB>() + ((nsd < 0 ? -nsd : nsd) - 1); nx = e->x; ny = e->y; }
+          }
+          if (sd != 0) {
+            if ((sd < 0) != flip) C::fe_neg(y, y);
+            // the second entry meets an accumulator with ZZ = ZZZ = 1: 4M + 2S instead of 8M + 2S (one of the nine additions of a
+            // 26-bit-window multiplication; the lanes of a wave disagree about `filled` only after a zero digit, 2^-WB per window)
+            if (filled == 1) { FbAcc<C>::add_affine(acc, x, y); filled = 2; }
+            else { FbAcc<C>::add_mixed(acc, x, y); filled = filled ? 2 : 1; }
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int j = 0; j < nwin_wide<C, WB>(); j++) {
+          const int sd = digit(j);
+          if (sd != 0) {
+            const AffEntry<C>* e = table + (size_t)j * wide_entries<WB>() + ((sd < 0 ? -sd : sd) - 1);
+            typename C::Fe x = e->x, y = e->y;
+            if ((sd < 0) != flip) C::fe_neg(y, y);
+            if (filled == 1) { FbAcc<C>::add_affine(acc, x, y); filled = 2; }
+            else { FbAcc<C>::add_mixed(acc, x, y); filled = filled ? 2 : 1; }
+          }
         }
       }
-#endif
       res[b] = acc;
       cnt = b + 1;
     }
