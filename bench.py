@@ -79,11 +79,11 @@ WORK = {
     # 10 signed 26-bit windows (21.5 GB table), XYZZ accumulator (round 3): the first entry is a copy, the second meets ZZ = ZZZ = 1
     # (4M+2S), 8 mixed additions 8M+2S, normalise 8M + (255S+12M)/64.  (Until then counted as 9 Jacobian additions 8M+3S and 6M+1S.)
     "p256_fixedbase": (4 + 8 * 8 + 8 + 12 / 64, 2 + 8 * 2 + 255 / 64),
-    # 96 windows x 4 doublings (4M+4S) + 89 mixed additions (97 digits x 15/16, first one a copy) + table as a co-Z chain (round 3:
-    # doubling with update 2M+4S, 6 co-Z additions 4M+2S, 6M for the last denominator = 32M+16S; until then 4 dbl + 3 general additions
-    # 11M+5S = 49M+31S) + table to affine through ONE inverted denominator and the chain's ratios (37M+7S; until then 8 x (6M+1S))
-    # + (385S+14M)/16 + output normalise 6M+1S + (385S+14M)/16 (16 units per lane and pass share the two inversions)
-    "p384_varbase": (1536 + 89 * 8 + 32 + 37 + 14 / 16 + 6 + 14 / 16, 1536 + 89 * 3 + 16 + 7 + 385 / 16 + 1 + 385 / 16),
+    # signed 5-bit windows since round 4 (77 positions): 76 x 5 doublings (4M+4S) + 73.6 mixed additions 8M+3S (77 digits x 31/32, the first one a
+    # copy) + table [P .. 16P] as a co-Z chain (doubling with update 2M+4S, 14 co-Z additions 4M+2S, 14M for the denominators = 72M+32S) + table to
+    # affine through ONE inverted denominator and the chain's ratios (77M+15S) + (385S+14M)/16 + output normalise 6M+1S + (385S+14M)/16 (16 units per
+    # lane and pass share the two inversions).  (Rounds 2-3: 4-bit windows, 96 x 4 doublings, 89 additions, 8-entry tables: 4 200 per unit.)
+    "p384_varbase": (1520 + (77 * 31 / 32 - 1) * 8 + 72 + 77 + 14 / 16 + 6 + 14 / 16, 1520 + (77 * 31 / 32 - 1) * 3 + 32 + 15 + 385 / 16 + 1 + 385 / 16),
     # bucket method with GLV halves, 7 windows of 18 / 19 bits at this size: 14 XYZZ mixed additions (8M+2S) per term;
     # per-term share of the endomorphism (1M), of the bucket pieces and of the bucket reduction (1.8 M buckets: XYZZ -> Jacobian
     # and two general additions 12M+4S each; 1.5 M pieces folded) ~ 9M + 3S
@@ -103,7 +103,7 @@ WORKLOADS = {
                            bytes_per_unit=32 + 65, kernel="fb::mul_wide_kernel<CurveP256,26,64,4>", pmc_match="P256Params>, 26, 64, 4",
                            desc="p256 mul_by_generator, 2^%d independent scalars per GPU, affine output"),
     "p384_varbase": dict(curve="p384", cid=2, log2n=22, fixed=False, msm=False, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
-                         bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,16,4>", pmc_match="vb::mul_kernel",
+                         bytes_per_unit=48 + 96 + 97, kernel="vb::mul_kernel<CurveP384,16,4,1,5>", pmc_match="vb::mul_kernel",
                          desc="p384 variable-base scalar multiplication, 2^%d independent (scalar, point) pairs per GPU, affine output"),
     "k256_msm": dict(curve="k256", cid=0, log2n=23, fixed=False, msm=True, metric="k256 MSM points/sec", unit="points/s",
                      bytes_per_unit=32 + 64, kernel="msm pipeline (digits / sort / bucket sums / reduce)", pmc_match="bucket_sum_kernel",

@@ -8,15 +8,15 @@
 namespace ecgpu {
 namespace vb {
 
-template <class C, int BATCH, int WAVES, int NT = 1>
+template <class C, int BATCH, int WAVES, int NT = 1, int WB = 4>
 __global__ void __launch_bounds__(256, WAVES) mul_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out, int out_fmt,
-                                                         uint8_t* out_inf, size_t n, LaneWs<C, BATCH>* ws_all) {
-  LaneWs<C, BATCH>& ws = ws_all[(size_t)blockIdx.x * blockDim.x + threadIdx.x];
-  __shared__ u32 lds_digits[NT * C::NW][256];
+                                                         uint8_t* out_inf, size_t n, LaneWs<C, BATCH, WB>* ws_all) {
+  LaneWs<C, BATCH, WB>& ws = ws_all[(size_t)blockIdx.x * blockDim.x + threadIdx.x];
+  __shared__ u32 lds_digits[NT * digit_words<C, WB>()][256];
   const DigitMem dm{&lds_digits[0][threadIdx.x], 256};
   const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (size_t base = tid; base < n; base += T * (BATCH / NT)) lane_pass<C, BATCH, NT>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, base, T, ws, dm);
+  for (size_t base = tid; base < n; base += T * (BATCH / NT)) lane_pass<C, BATCH, NT, WB>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, base, T, ws, dm);
 }
 
 }  // namespace vb

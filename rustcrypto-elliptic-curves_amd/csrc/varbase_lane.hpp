@@ -22,11 +22,16 @@ template <class C> constexpr int nwin() { return 2 * C::NB + 1; }   // nibbles +
 // workspace of one lane: BATCH tables of 8 points - entry e is (e + 1) P as (x, y) over the denominator D_e of the co-Z chain,
 // overwritten by the affine x, y; its z slot holds the chain's ratio D_e / D_(e-1) (entries 2 .. 7), D_1 (entry 1) and D_7
 // (entry 0, whose x, y are P rewritten to D_7) - and the BATCH prefix products of the shared inversion
-template <class C, int BATCH>
+template <class C, int BATCH, int WB = 4>
 struct LaneWs {
-  Jac<C> tab[BATCH][8];
+  Jac<C> tab[BATCH][1 << (WB - 1)];
   typename C::Fe pre[BATCH];
 };
+// WB = window width in bits: 4 (8 table entries, 8 NW + 1 digit positions: signed nibbles of k + 0x88..8) or 5 (16 entries, ceil((32 NW + 1) / 5)
+// positions: 5-bit fields of k + 0x..10842 1084 2108 4210, one word more than the scalar).  Round 4, P-384: a table entry costs ~13 multiplications
+// since the co-Z chains, an addition 11: 77 windows and 8 more entries instead of 97 windows save ~75 of 4 200 multiplications.
+template <class C, int WB> constexpr int positions() { return WB == 4 ? 8 * C::NW + 1 : (32 * C::NW + 1 + WB - 1) / WB; }
+template <class C, int WB> constexpr int digit_words() { return WB == 4 ? C::NW : C::NW + 1; }
 
 // One pass of one lane: units base, base + T, .., base + (BATCH / NT - 1) T (those below n).  A unit is a linear
 // combination of NT terms (NT = 1: k * P; NT = 2: LinearCombination::lincomb, k P + l Q, primeorder/src/projective.rs:
@@ -42,11 +47,15 @@ struct LaneWs {
 // Measured against Jacobian tables with general additions: +8.5 % for P-384 (16.6 against 15.3 M/s at 2^21), +3.7 % for
 // P-256 (53.2 against 51.3; in round 1, with a square-and-multiply inversion of 384 multiplications instead of the
 // 267-multiplication chain, the extra pass over the tables cost P-256 more than the cheaper additions saved).
-template <class C, int BATCH, int NT = 1>
+template <class C, int BATCH, int NT = 1, int WB = 4>
 ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf, size_t n, size_t base,
-                        size_t T, LaneWs<C, BATCH>& ws, const DigitMem& dm) {
+                        size_t T, LaneWs<C, BATCH, WB>& ws, const DigitMem& dm) {
   static_assert(BATCH % NT == 0 && BATCH <= 32, "table slots per pass");
+  static_assert(WB == 4 || WB == 5, "window width");
   constexpr int NW = C::NW;
+  constexpr int NE = 1 << (WB - 1);            // table entries [P .. NE P]
+  constexpr int DW = digit_words<C, WB>();     // recoded words per term kept in DigitMem
+  constexpr int NPOS = positions<C, WB>();
   constexpr int UB = BATCH / NT;               // units per pass
   using Fe = typename C::Fe;
   Jac<C> res[UB];
@@ -102,12 +111,12 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
     jac::coz_double_update<C>(rx, ry, zacc, qx, qy, p, pt_fmt != FMT_PROJECTIVE);
     tab[1].x = rx; tab[1].y = ry;
 #pragma unroll 1
-    for (int e = 2; e < 8; e++) {
+    for (int e = 2; e < NE; e++) {
       jac::coz_add_update<C>(rx, ry, qx, qy, h);
       tab[e].x = rx; tab[e].y = ry; tab[e].z = h;
       C::fe_mul(zacc, zacc, h);                // D_e = D_(e-1) h_e
     }
-    tab[0].x = qx; tab[0].y = qy; tab[0].z = zacc;       // P over D_7, and D_7 itself
+    tab[0].x = qx; tab[0].y = qy; tab[0].z = zacc;       // P over D_(NE-1), and D_(NE-1) itself
   }
   // ---- phase B: one inversion for the D_7 of all cnt * NT tables (a zero denominator - only possible for input that is
   //      not on the curve - is replaced by one so that it cannot poison its neighbours); 1 / D_e = (1 / D_7) prod_{i > e} h_i
@@ -130,14 +139,14 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
       C::fe_mul(zi7, ai, ws.pre[s]);
       C::fe_mul(ai, ai, z);
       C::fe_sqr(t, zi7);
-      C::fe_mul(tab[7].x, tab[7].x, t);
+      C::fe_mul(tab[NE - 1].x, tab[NE - 1].x, t);
       C::fe_mul(tab[0].x, tab[0].x, t);
       C::fe_mul(t, t, zi7);
-      C::fe_mul(tab[7].y, tab[7].y, t);
+      C::fe_mul(tab[NE - 1].y, tab[NE - 1].y, t);
       C::fe_mul(tab[0].y, tab[0].y, t);
 #pragma unroll 1
-      for (int e = 6; e >= 1; e--) {
-        if (e == 6) sfx = tab[7].z; else C::fe_mul(sfx, sfx, tab[e + 1].z);      // D_7 / D_e
+      for (int e = NE - 2; e >= 1; e--) {
+        if (e == NE - 2) sfx = tab[NE - 1].z; else C::fe_mul(sfx, sfx, tab[e + 1].z);      // D_(NE-1) / D_e
         C::fe_mul(zi, zi7, sfx);
         C::fe_sqr(t, zi);
         C::fe_mul(tab[e].x, tab[e].x, t);
@@ -166,43 +175,65 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
       if ((flips >> s) & 1u) { mp_sub<NW>(t, ord, k); mp_copy<NW>(k, t); }
       u32 c = 0;
       const bool skip = (infs >> s) & 1u;       // an identity input contributes nothing: all its digits read as zero
+      if constexpr (WB == 4) {
 #pragma unroll
-      for (int w = 0; w < NW; w++) {
-        const u32 yw = addc(k[w], 0x88888888u, c);
+        for (int w = 0; w < NW; w++) {
+          const u32 yw = addc(k[w], 0x88888888u, c);
 #ifdef ECGPU_DIGITS_IN_REGISTERS
-        y[tt][w] = skip ? 0x88888888u : yw;
+          y[tt][w] = skip ? 0x88888888u : yw;
 #else
-        dm.st(tt * NW + w, skip ? 0x88888888u : yw);
+          dm.st(tt * NW + w, skip ? 0x88888888u : yw);
 #endif
+        }
+        carry[tt] = skip ? 0u : c;
+      } else {
+        // 5-bit fields: t = k + sum_j 16 * 32^j, digit_j = field_j(t) - 16 in [-16, 15]; k <= n / 2 < 2^(32 NW - 1) keeps t below 32^NPOS
+#pragma unroll
+        for (int w = 0; w <= NW; w++) {
+          // word w of the constant 0x...4210842108421084 2108...: bit b is set iff b = 4 (mod 5), for b below 5 NPOS
+          u32 cw = 0;
+#pragma unroll
+          for (int b = 0; b < 32; b++) cw |= (((32 * w + b) % 5 == 4) && (32 * w + b < 5 * NPOS)) ? (1u << b) : 0u;
+          const u32 yw = addc(w < NW ? k[w] : 0u, cw, c);
+          dm.st(tt * DW + w, skip ? cw : yw);
+        }
+        carry[tt] = 0u;
       }
-      carry[tt] = skip ? 0u : c;
     }
     Jac<C> acc;
     jac::set_infinity<C>(acc);
 #pragma unroll 1
-    for (int j = 8 * NW; j >= 0; j--) {         // position 8 NW holds the carry digits (0 or 1)
-      if (j != 8 * NW) {
+    for (int j = NPOS - 1; j >= 0; j--) {       // WB = 4: position 8 NW holds the carry digits (0 or 1)
+      if (j != NPOS - 1) {
 #pragma unroll 1
-        for (int d = 0; d < 4; d++) jac::dbl<C>(acc);
+        for (int d = 0; d < WB; d++) jac::dbl<C>(acc);
       }
 #pragma unroll 1
       for (int tt = 0; tt < NT; tt++) {
         int sd;
-        if (j == 8 * NW) {
-          sd = 0;
+        if constexpr (WB == 4) {
+          if (j == 8 * NW) {
+            sd = 0;
 #pragma unroll
-          for (int q = 0; q < NT; q++) sd = (q == tt) ? (int)carry[q] : sd;
-        } else {
+            for (int q = 0; q < NT; q++) sd = (q == tt) ? (int)carry[q] : sd;
+          } else {
 #ifdef ECGPU_DIGITS_IN_REGISTERS
-          u32 word = y[0][0];
+            u32 word = y[0][0];
 #pragma unroll
-          for (int r = 0; r < NT; r++)
+            for (int r = 0; r < NT; r++)
 #pragma unroll
-            for (int q = 0; q < NW; q++) word = (r == tt && (j >> 3) == q) ? y[r][q] : word;
+              for (int q = 0; q < NW; q++) word = (r == tt && (j >> 3) == q) ? y[r][q] : word;
 #else
-          const u32 word = dm.ld(tt * NW + (j >> 3));
+            const u32 word = dm.ld(tt * NW + (j >> 3));
 #endif
-          sd = (int)((word >> (4 * (j & 7))) & 15u) - 8;
+            sd = (int)((word >> (4 * (j & 7))) & 15u) - 8;
+          }
+        } else {
+          // field j of the recoded words: bits 5 j .. 5 j + 4, possibly across a word boundary (the addresses are wave-uniform)
+          const int bit = 5 * j, wi = bit >> 5, sh = bit & 31;
+          const u32 lo = dm.ld(tt * DW + wi);
+          const u32 hi = (sh > 27) ? dm.ld(tt * DW + wi + 1) : 0u;      // wi + 1 <= NW: the top field ends inside word NW
+          sd = (int)((u32)((((u64)hi << 32) | lo) >> sh) & 31u) - 16;
         }
         if (sd != 0) {
           const Jac<C>& e = ws.tab[b * NT + tt][(sd < 0 ? -sd : sd) - 1];

@@ -112,6 +112,24 @@ static int vb_walk(const uint8_t* scalars, const uint8_t* points, int pt_fmt, ui
   free(ws);
   return 0;
 }
+// the 5-bit-window form (16 table entries, ceil((32 NW + 1) / 5) positions), 16 slots per pass
+template <class C>
+static int vb_walk5(const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n, size_t lanes) {
+  using Ws = vb::LaneWs<C, 16, 5>;
+  Ws* ws = (Ws*)malloc(sizeof(Ws));
+  u32 digits[vb::digit_words<C, 5>()];
+  const DigitMem dm{digits, 1};
+  for (size_t tid = 0; tid < lanes; tid++)
+    for (size_t base = tid; base < n; base += lanes * 16)
+      vb::lane_pass<C, 16, 1, 5>((const u32*)scalars, (const u32*)points, pt_fmt, (u32*)out, out_fmt, out_inf, n, base, lanes, *ws, dm);
+  free(ws);
+  return 0;
+}
+extern "C" int ht_vb_mul_w5(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, uint8_t* out, int out_fmt, uint8_t* out_inf, size_t n,
+                            size_t lanes) {
+  return curve == 1 ? vb_walk5<CurveP256>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes)
+                    : vb_walk5<CurveP384>(scalars, points, pt_fmt, out, out_fmt, out_inf, n, lanes);
+}
 // n units of `terms` (1 or 2) terms each
 extern "C" int ht_vb_lincomb(int curve, const uint8_t* scalars, const uint8_t* points, int pt_fmt, int terms, uint8_t* out, int out_fmt, uint8_t* out_inf,
                              size_t n, size_t lanes) {

@@ -130,9 +130,9 @@ def test_vbct_slot_counts_and_passes(cn, cid, lanes, n):
 
 
 @pytest.mark.parametrize("cn,cid", CURVES)
-@pytest.mark.parametrize("fn", ["ht_vbct_mul16", "ht_vb_mul16"])
+@pytest.mark.parametrize("fn", ["ht_vbct_mul16", "ht_vb_mul16", "ht_vb_mul_w5"])
 def test_sixteen_slots_per_pass(cn, cid, fn):
-    if cid == 0 and fn == "ht_vb_mul16":
+    if cid == 0 and fn != "ht_vbct_mul16":
         pytest.skip("the public-data k256 kernel is mulfast_k256.hpp (tests/test_hosttwin_k256_fast.py)")
     """The product's pass size (16 table slots per lane and pass): 2 lanes, 53 units = one full pass and a ragged second one
     (11 and 10 slots), for the constant-time body and for the public-data body."""
@@ -224,3 +224,25 @@ def test_offcurve_small_order_point_does_not_poison_its_lane(cn, cid, fn):
             continue                               # unspecified output for input that violates the reference's type invariant
         want = M.affine_mul(c, ks[i] % c.n, ps[i])
         assert out[2 * nb * i:2 * nb * (i + 1)] == M.i2b(c, want[0]) + M.i2b(c, want[1]) and inf[i] == 0, i
+
+
+@pytest.mark.parametrize("cn,cid", [("p256", 1), ("p384", 2)])
+def test_five_bit_windows_edge_scalars(cn, cid):
+    """The 5-bit-window form of the public-data variable-base body (csrc/varbase_lane.hpp, WB = 5: 16 table entries, digits = 5-bit
+    fields of k' + 0x..108421 minus 16): every edge scalar of the recoding - digits -16 and 15, fields that straddle a word boundary,
+    the top field, k' = (n - 1) / 2 - and random ones, against the model; identity inputs; two lanes, three passes."""
+    c = M.CURVES[cn]
+    nb = c.nbytes
+    ks = edge_scalars(c) + [int("f" * (2 * nb), 16) % c.n, int("0" + "f" * (2 * nb - 1), 16) % c.n] + [16 * 32 ** j for j in (0, 1, 6, 7, 12, 13, 50)] + \
+         [(31 * 32 ** j + 15) % c.n for j in (1, 6, 12, 51)] + [synth.scalar(c, 8000 + i) for i in range(20)]
+    n = len(ks)
+    ps = [synth.point(c, 8100 + (i % 7)) for i in range(n)]
+    ps[4] = None
+    out, inf = _vbct(cid, c, ks, ps, 2, fn="ht_vb_mul_w5")
+    for i in range(n):
+        want = None if ps[i] is None else M.affine_mul(c, ks[i] % c.n, ps[i])
+        got = out[2 * nb * i:2 * nb * (i + 1)]
+        if want is None:
+            assert got == bytes(2 * nb) and inf[i] == 1, (i, hex(ks[i]))
+        else:
+            assert got == M.i2b(c, want[0]) + M.i2b(c, want[1]) and inf[i] == 0, (i, hex(ks[i]))
