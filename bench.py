@@ -64,18 +64,18 @@ MAC_ISSUED = {"k256": (72, 53), "p256": (88, 88), "p384": (168, 126)}
 # one reduction for both): 8 fold products less per addition in the ISSUED count; the algorithmic count (two multiplications) stays.
 # The secp256k1 doubling does the same with Y3 = E (D - X3) - 8 B^2: the squaring B^2 becomes the second product of the fused form (72 issued
 # products instead of 53, no fold of its own: + 19 - 8 = + 11 per doubling; FUSED_DBL).
-FUSED_PAIRS = {"k256_varbase_fast": 66 * 15 / 16, "k256_msm": 14, "k256_ecdsa_verify": 66 * 15 / 16 + 11}
-FUSED_DBL = {"k256_varbase_fast": 128, "k256_ecdsa_verify": 128}
+FUSED_PAIRS = {"k256_varbase_fast": 52 * 31 / 32, "k256_msm": 14, "k256_ecdsa_verify": 52 * 31 / 32 + 11}
+FUSED_DBL = {"k256_varbase_fast": 125, "k256_ecdsa_verify": 125}
 
 WORK = {
     # reference schedule: 128 doublings (6M+2S) + 80 complete additions (12M) + to_affine (255S + 17M)
     "k256_varbase_ref": (128 * 6 + 80 * 12 + 17, 128 * 2 + 255),
-    # throughput schedule (csrc/mulfast_k256.hpp), batch of 32 results per inversion
-    #   table   : co-Z chain (round 3): doubling with update 2M+4S + 6 co-Z additions (4M+2S, no Z) + rescale of 6 entries
-    #             6M + 6x(3M+1S) + common Z 1M + 8 beta*x (until then 1 dbl + 6 mixed adds + rescale of 7: 87M + 29S)  =  59M + 22S
-    #   loop    : 128 dbl (3M+4S) + 66 * 15/16 mixed adds (8M+3S)                                      = 879M + 697.6S
-    #   output  : 2M (global Z) + batched normalise 6M+1S + (255S+15M)/32                              =   9M +   9S
-    "k256_varbase_fast": (59 + 128 * 3 + 66 * 15 / 16 * 8 + 9, 22 + 128 * 4 + 66 * 15 / 16 * 3 + 9),
+    # throughput schedule (csrc/mulfast_k256.hpp), batch of 32 results per inversion; signed 5-bit windows since round 4 (26 positions per GLV half)
+    #   table   : [P .. 16P] as a co-Z chain: doubling with update 2M+4S + 14 co-Z additions (4M+2S, no Z) + rescale of 14 entries
+    #             14x(4M+1S) + 16 beta*x + common Z 1M                                                   = 131M +  46S   (8 entries until round 3: 59M + 22S)
+    #   loop    : 25 x 5 dbl (3M+4S) + 52 * 31/32 mixed adds (8M+3S)                                     = 778M + 651.1S (4-bit windows: 128 dbl, 66 * 15/16 adds)
+    #   output  : 2M (global Z) + batched normalise 6M+1S + (255S+15M)/32                                =   9M +   9S
+    "k256_varbase_fast": (131 + 125 * 3 + 52 * 31 / 32 * 8 + 9, 46 + 125 * 4 + 52 * 31 / 32 * 3 + 9),
     # 10 signed 26-bit windows (21.5 GB table), XYZZ accumulator (round 3): the first entry is a copy, the second meets ZZ = ZZZ = 1
     # (4M+2S), 8 mixed additions 8M+2S, normalise 8M + (255S+12M)/64.  (Until then counted as 9 Jacobian additions 8M+3S and 6M+1S.)
     "p256_fixedbase": (4 + 8 * 8 + 8 + 12 / 64, 2 + 8 * 2 + 255 / 64),
@@ -89,7 +89,7 @@ WORK = {
     # and two general additions 12M+4S each; 1.5 M pieces folded) ~ 9M + 3S
     "k256_msm": (14 * 8 + 1 + 9, 14 * 2 + 3),
     # verification = u2 Q (headline kernel) + u1 G (20-bit table at this batch size) + prep / check (57 scalar-field equivalents + 7)
-    "k256_ecdsa_verify": (59 + 128 * 3 + 66 * 15 / 16 * 8 + 9 + 4 + 11 * 8 + 8 + 64, 22 + 128 * 4 + 66 * 15 / 16 * 3 + 9 + 2 + 11 * 2 + 4),
+    "k256_ecdsa_verify": (131 + 125 * 3 + 52 * 31 / 32 * 8 + 9 + 4 + 11 * 8 + 8 + 64, 46 + 125 * 4 + 52 * 31 / 32 * 3 + 9 + 2 + 11 * 2 + 4),
     # p256 verification = u2 Q (vb::mul_kernel<CurveP256,16,4>: 256 doublings 4M+4S, 60 general additions 11M+5S, table 4 dbl + 3 add,
     # output normalise 6M+1S + (255S+12M)/8 = 1 740 M + 1 388 S; counted with 8 units per inversion, 16 since round 3: -1 %) + u1 G (20-bit table, XYZZ: 100 M + 28 S) + prep / check (~64 M)
     "p256_ecdsa_verify": (1740 - 28 + 100 + 64, 1388 - 16 + 28),     # - 28 M, - 16 S: the co-Z table chain of round 3
@@ -830,7 +830,7 @@ def main():
                                             world, (" (%s, world %d)" % (args.backend, world)) if dist is not None else " (no process group at N = 1)"))
                                        if wl["msm"] else ("independent batches, %d GPU(s), no collective" % world)),
                        "schedule": ("reference-faithful (GLV + signed radix-16, RCB complete formulas, constant-time table scans, per-point inversion)" if args.schedule == "ref"
-                                    else "throughput (GLV + signed radix-16, Jacobian, common-Z table, batched inversion)")
+                                    else "throughput (GLV + signed 5-bit windows, Jacobian, common-Z table of 16 entries, batched inversion)")
                        if args.workload == "k256_varbase" else "throughput schedule of this workload (DESIGN.md section 4)"},
             "parity_ok": res["parity"],
             "parity_checked": res["checked"],

@@ -263,25 +263,21 @@ __global__ void __launch_bounds__(256, ECGPU_REF_WAVES) k256_lincomb_ref_n_kerne
 // move with BATCH: the BATCH results and prefix products live in the private segment by design).
 // ---------------------------------------------------------------------------------------------
 struct K256FastPrep {
-  u32 y1[4], y2[4];     // recoded magnitudes of the two GLV halves (radix16_recode)
-  u32 top1, top2;       // 33rd digits
-  u32 neg1, neg2;       // signs of the halves
+  u32 w1[K256_DW], w2[K256_DW];   // recoded digits of the two GLV halves (k256::recode_half)
+  u32 neg1, neg2;                 // signs of the halves
   u32 p_inf;
-  FeK256 zfix;          // common table denominator times the input's own Z
+  FeK256 zfix;                    // common table denominator times the input's own Z
 };
 
+template <int WB>
 __device__ __forceinline__ void k256_fast_prep(K256FastPrep* pp, TabSlotK256* tab, const u32* sc, const u32* src, int pt_fmt) {
   u32 k[8];
   words_load_be<8>(k, sc);
   k256::scalar_reduce_once(k);
   k256::GlvSplit s;
   k256::glv_split(s, k);
-  k256::Radix16<4> d1, d2;
-  k256::radix16_recode<4>(d1, s.k1);
-  k256::radix16_recode<4>(d2, s.k2);
-#pragma unroll
-  for (int i = 0; i < 4; i++) { pp->y1[i] = d1.y[i]; pp->y2[i] = d2.y[i]; }
-  pp->top1 = d1.top; pp->top2 = d2.top;
+  k256::recode_half<WB>(pp->w1, s.k1);
+  k256::recode_half<WB>(pp->w2, s.k2);
   pp->neg1 = s.neg1; pp->neg2 = s.neg2;
 
   FeK256 px, py, pz;
@@ -309,29 +305,27 @@ __device__ __forceinline__ void k256_fast_prep(K256FastPrep* pp, TabSlotK256* ta
   }
   pp->p_inf = p_inf ? 1u : 0u;
   FeK256 zg;
-  k256::table_build_globalz(tab, zg, px, py);
+  k256::table_build_globalz<WB>(tab, zg, px, py);
   k256::mul(pp->zfix, zg, pz);
 }
 
+template <int WB>
 __device__ __forceinline__ void k256_fast_loop(JacK256* out, const K256FastPrep* pp, const TabSlotK256* tab) {
-  u32 y1[4], y2[4];
+  constexpr int NPOS = K256Win<WB>::NPOS;
+  u32 w1[K256_DW], w2[K256_DW];
 #pragma unroll
-  for (int i = 0; i < 4; i++) { y1[i] = pp->y1[i]; y2[i] = pp->y2[i]; }
+  for (int i = 0; i < K256_DW; i++) { w1[i] = pp->w1[i]; w2[i] = pp->w2[i]; }
   const bool n1 = pp->neg1 != 0, n2 = pp->neg2 != 0;
   JacK256 acc;
   k256::set_zero(acc.x); k256::set_zero(acc.y); k256::set_zero(acc.z);      // infinity
-  // digit 32 (the carry digits) then digits 31..0; one shared body for all 33 positions
+  // the top position (WB = 4: the carry digits) then the others; one shared body for all positions
 #pragma unroll 1
-  for (int i = 32; i >= 0; i--) {
-    if (i != 32) {
+  for (int i = NPOS - 1; i >= 0; i--) {
+    if (i != NPOS - 1) {
 #pragma unroll 1
-      for (int j = 0; j < 4; j++) k256::jac_double(acc);
+      for (int j = 0; j < WB; j++) k256::jac_double(acc);
     }
-    u32 w1 = y1[0], w2 = y2[0];
-#pragma unroll
-    for (int q = 1; q < 4; q++) { w1 = (i >> 3) == q ? y1[q] : w1; w2 = (i >> 3) == q ? y2[q] : w2; }
-    int dg1 = k256::radix16_digit(w1, i & 7), dg2 = k256::radix16_digit(w2, i & 7);
-    if (i == 32) { dg1 = (int)pp->top1; dg2 = (int)pp->top2; }
+    const int dg1 = k256::half_digit<WB>(w1, i), dg2 = k256::half_digit<WB>(w2, i);
 #pragma unroll 1
     for (int h = 0; h < 2; h++) k256::add_digit(acc, tab, h ? dg2 : dg1, h != 0, h ? n2 : n1);
   }
@@ -350,12 +344,13 @@ __device__ __forceinline__ void k256_fast_finish(const JacK256* res, FeK256* pre
 // k256 mul.rs:313-323 with N = 2: the ECDSA-verify shape u1*G + u2*Q).  Each term gets its own common-Z
 // table; the two tables live on curves isomorphic by different factors, so each is rescaled by the other's
 // factor (x u^2, y u^3) to put both on the curve isomorphic by zfix0 * zfix1.
+template <int WB>
 __device__ __forceinline__ void k256_fast_rescale(TabSlotK256* tab, const FeK256& s) {
   FeK256 s2, s3;
   k256::sqr(s2, s);
   k256::mul(s3, s2, s);
 #pragma unroll 1
-  for (int j = 0; j < 8; j++) {
+  for (int j = 0; j < K256Win<WB>::NE; j++) {
     FeK256 y;
     constexpr int SS = K256_SLOT_STRIDE;
     k256::mul(tab[SS * j].x, tab[SS * j].x, s2);
@@ -368,7 +363,8 @@ __device__ __forceinline__ void k256_fast_rescale(TabSlotK256* tab, const FeK256
 template <int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k256_lincomb2_fast_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out,
                                                                  int out_fmt, uint8_t* out_inf, size_t n, TabSlotK256* table_ws) {
-  TabSlotK256* tab = table_ws + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (2 * K256_TAB_SLOTS);
+  constexpr int WB = 4, SLOTS = K256Win<WB>::SLOTS, NPOS = K256Win<WB>::NPOS;       // 4-bit windows: this kernel rescales both tables entry by entry (5 bits: -6 %)
+  TabSlotK256* tab = table_ws + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (2 * SLOTS);
   K256FastPrep prep[2];
   JacK256 res[BATCH];
   FeK256 pre[BATCH];
@@ -382,28 +378,23 @@ __global__ void __launch_bounds__(256, WAVES) k256_lincomb2_fast_kernel(const u3
       const size_t i = base + (size_t)j * T;
       if (i >= n) break;
 #pragma unroll 1
-      for (int t = 0; t < 2; t++) k256_fast_prep(&prep[t], tab + t * K256_TAB_SLOTS, scalars + (2 * i + t) * 8, points + (2 * i + t) * pw, pt_fmt);
+      for (int t = 0; t < 2; t++) k256_fast_prep<WB>(&prep[t], tab + t * SLOTS, scalars + (2 * i + t) * 8, points + (2 * i + t) * pw, pt_fmt);
 #pragma unroll 1
-      for (int t = 0; t < 2; t++) k256_fast_rescale(tab + t * K256_TAB_SLOTS, prep[1 - t].zfix);
+      for (int t = 0; t < 2; t++) k256_fast_rescale<WB>(tab + t * SLOTS, prep[1 - t].zfix);
       JacK256 acc;
       k256::set_zero(acc.x); k256::set_zero(acc.y); k256::set_zero(acc.z);
 #pragma unroll 1
-      for (int w = 32; w >= 0; w--) {
-        if (w != 32) {
+      for (int w = NPOS - 1; w >= 0; w--) {
+        if (w != NPOS - 1) {
 #pragma unroll 1
-          for (int d = 0; d < 4; d++) k256::jac_double(acc);
+          for (int d = 0; d < WB; d++) k256::jac_double(acc);
         }
 #pragma unroll 1
         for (int h = 0; h < 4; h++) {
           const K256FastPrep* pp = &prep[h >> 1];
-          const u32* y = (h & 1) ? pp->y2 : pp->y1;
-          u32 word = y[0];
-#pragma unroll
-          for (int q = 1; q < 4; q++) word = (w >> 3) == q ? y[q] : word;
-          int dg = k256::radix16_digit(word, w & 7);
-          if (w == 32) dg = (int)((h & 1) ? pp->top2 : pp->top1);
+          int dg = k256::half_digit<WB>((h & 1) ? pp->w2 : pp->w1, w);
           if (pp->p_inf) dg = 0;                       // an identity input contributes nothing
-          k256::add_digit(acc, tab + (h >> 1) * K256_TAB_SLOTS, dg, (h & 1) != 0, ((h & 1) ? pp->neg2 : pp->neg1) != 0);
+          k256::add_digit(acc, tab + (h >> 1) * SLOTS, dg, (h & 1) != 0, ((h & 1) ? pp->neg2 : pp->neg1) != 0);
         }
       }
       FeK256 zf;
@@ -420,7 +411,8 @@ template <int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k256_mul_fast_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out,
                                                             int out_fmt, uint8_t* out_inf, size_t n, TabSlotK256* table_ws) {
   // this lane's table: 16 slots x 64 B, contiguous, in the launch's global workspace (gridDim * 256 lanes)
-  TabSlotK256* tab = table_ws + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * K256_TAB_SLOTS;
+  constexpr int WB = K256_WB;
+  TabSlotK256* tab = table_ws + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * K256Win<WB>::SLOTS;
   K256FastPrep prep;
   JacK256 res[BATCH];
   FeK256 pre[BATCH];
@@ -433,8 +425,8 @@ __global__ void __launch_bounds__(256, WAVES) k256_mul_fast_kernel(const u32* sc
     for (int j = 0; j < BATCH; j++) {
       const size_t i = base + (size_t)j * T;
       if (i >= n) break;
-      k256_fast_prep(&prep, tab, scalars + i * 8, points + i * pw, pt_fmt);
-      k256_fast_loop(&res[j], &prep, tab);
+      k256_fast_prep<WB>(&prep, tab, scalars + i * 8, points + i * pw, pt_fmt);
+      k256_fast_loop<WB>(&res[j], &prep, tab);
       cnt = j + 1;
     }
     k256_fast_finish(res, pre, cnt, base, T, out, out_fmt, out_inf);

@@ -31,13 +31,28 @@ struct alignas(16) TabSlotK256 {
 };
 // ECGPU_K256_NO_BETA_SLOTS (A/B switch): 8 slots of (x, y) only, 512 B per lane; the lambda half multiplies x by beta when it
 // reads an entry (one more multiplication on half of the additions) instead of keeping beta*x beside x (1 KB per lane).
+// Window width of the throughput schedule in bits (template parameter WB of the table / digit functions below).  4 (rounds 1-3): table
+// [P .. 8P], 33 digit positions per GLV half (32 signed nibbles and the carry digit), 4 doublings per position.  5 (round 4): table [P .. 16P],
+// 26 positions (5-bit fields of |k_i| + 0x...1084210842 minus 16; |k_i| < 2^128 leaves the top field room for the last carry), 5 doublings per
+// position: 11.5 additions less per unit for 8 more table entries.  Measured (profiles/r04_ab_measurements.txt, set four): single-term
+// multiplication 134.6-135.0 -> 131.0-131.5 ms per 2^24 (-2.7 %): K256_WB = 5 is its default; the two-term kernel, which rescales both of its
+// tables entry by entry, loses 6 % with 16 entries and stays on 4 bits.
+#ifndef K256_WB
+#define K256_WB 5
+#endif
 #ifdef ECGPU_K256_NO_BETA_SLOTS
-constexpr int K256_TAB_SLOTS = 8;
 constexpr int K256_SLOT_STRIDE = 1;
 #else
-constexpr int K256_TAB_SLOTS = 16;
 constexpr int K256_SLOT_STRIDE = 2;
 #endif
+template <int WB>
+struct K256Win {
+  static_assert(WB == 4 || WB == 5, "window width");
+  static constexpr int NE = 1 << (WB - 1);                        // table entries
+  static constexpr int NPOS = (WB == 4) ? 33 : 26;                // digit positions per half
+  static constexpr int SLOTS = K256_SLOT_STRIDE * NE;             // 64-byte table slots per term
+};
+constexpr int K256_DW = 5;                                        // recoded words per half (WB = 4: four words and the carry digit)
 
 namespace k256 {
 
@@ -161,28 +176,30 @@ ECGPU_HD void coz_add_update(FeK256& rx, FeK256& ry, FeK256& qx, FeK256& qy, FeK
 // The chain 2P, 3P = 2P + P, .. runs in co-Z form (round 3: 6 + 6 x 6 multiplications instead of 7 + 6 x 11): every step
 // rewrites P to the denominator of the new multiple, so the additions are co-Z additions, no Z is ever multiplied out (only
 // the ratios h_j = Z_(j+1) / Z_j are kept) and the last rewritten P IS entry 0 at the common denominator.
+template <int WB>
 ECGPU_HD void table_build_globalz(TabSlotK256* tab, FeK256& zglobal, const FeK256& px, const FeK256& py) {
-  FeK256 mx[8], my[8];   // (mx[j], my[j]) = (j+1) P over the denominator Z_j;  Z_1 = 2 y, Z_j = Z_(j-1) zr[j]
-  FeK256 zr[8];
+  constexpr int NE = K256Win<WB>::NE;
+  FeK256 mx[NE], my[NE];   // (mx[j], my[j]) = (j+1) P over the denominator Z_j;  Z_1 = 2 y, Z_j = Z_(j-1) zr[j]
+  FeK256 zr[NE];
   JacK256 d;
   FeK256 qx, qy;
   coz_double_affine(d, qx, qy, px, py);
   mx[1] = d.x; my[1] = d.y;
   FeK256 rx = d.x, ry = d.y;
 #pragma unroll 1
-  for (int j = 2; j < 8; j++) {
+  for (int j = 2; j < NE; j++) {
     coz_add_update(rx, ry, qx, qy, zr[j]);
     mx[j] = rx; my[j] = ry;
   }
   FeK256 beta_; beta(beta_);
-  // scale (j+1)P to the denominator of 8P: s_j = Z7 / Z_j = prod_{i > j} zr[i]
+  // scale (j+1)P to the denominator of NE P: s_j = Z_(NE-1) / Z_j = prod_{i > j} zr[i]
   FeK256 s; set_one(s);
   constexpr int SS = K256_SLOT_STRIDE;
-  tab[7 * SS].x = mx[7]; tab[7 * SS].y = my[7];
-  if constexpr (SS == 2) { tab[15].y = my[7]; mul(tab[15].x, mx[7], beta_); }
+  tab[(NE - 1) * SS].x = mx[NE - 1]; tab[(NE - 1) * SS].y = my[NE - 1];
+  if constexpr (SS == 2) { tab[2 * NE - 1].y = my[NE - 1]; mul(tab[2 * NE - 1].x, mx[NE - 1], beta_); }
 #pragma unroll 1
-  for (int j = 6; j >= 1; j--) {
-    mul(s, s, zr[j + 1]);                    // s = Z7 / Z_j
+  for (int j = NE - 2; j >= 1; j--) {
+    mul(s, s, zr[j + 1]);                    // s = Z_(NE-1) / Z_j
     FeK256 s2, s3;
     sqr(s2, s);
     mul(s3, s2, s);
@@ -192,9 +209,46 @@ ECGPU_HD void table_build_globalz(TabSlotK256* tab, FeK256& zglobal, const FeK25
     tab[SS * j].x = tx; tab[SS * j].y = ty;
     if constexpr (SS == 2) { tab[2 * j + 1].y = ty; mul(tab[2 * j + 1].x, tx, beta_); }
   }
-  mul(zglobal, s, d.z);                      // Z7 = (Z7 / Z_1) 2y
-  tab[0].x = qx; tab[0].y = qy;              // P over Z7: the last rewrite of the chain
+  mul(zglobal, s, d.z);                      // Z_(NE-1) = (Z_(NE-1) / Z_1) 2y
+  tab[0].x = qx; tab[0].y = qy;              // P over Z_(NE-1): the last rewrite of the chain
   if constexpr (SS == 2) { tab[1].y = qy; mul(tab[1].x, qx, beta_); }
+}
+
+// Recoded digits of one GLV half (|k| < 2^128, four words).  w[0 .. 4]: WB = 4: k + 0x8888.. and the carry digit; WB = 5: the five
+// words of k + sum_j 16 * 32^j (130 bits).  half_digit(w, j) = the signed digit at position j, j < K256_NPOS.
+template <int WB>
+ECGPU_HD void recode_half(u32* w, const u32* k) {
+  u32 c = 0;
+  if constexpr (WB == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = addc(k[i], 0x88888888u, c);
+    w[4] = c;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      u32 cw = 0;                              // bit b of the constant is set iff b = 4 (mod 5), b < 5 NPOS
+#pragma unroll
+      for (int b = 0; b < 32; b++) cw |= (((32 * i + b) % 5 == 4) && (32 * i + b < 5 * K256Win<WB>::NPOS)) ? (1u << b) : 0u;
+      w[i] = addc(i < 4 ? k[i] : 0u, cw, c);
+    }
+  }
+}
+template <int WB>
+ECGPU_HD int half_digit(const u32* w, int j) {       // j is wave-uniform: the selects below are not divergent
+  if constexpr (WB == 4) {
+    if (j == 32) return (int)w[4];
+    u32 word = w[0];
+#pragma unroll
+    for (int q = 1; q < 4; q++) word = (j >> 3) == q ? w[q] : word;
+    return (int)((word >> (4 * (j & 7))) & 15u) - 8;
+  } else {
+    const int bit = 5 * j, wi = bit >> 5, sh = bit & 31;
+    u32 lo = w[0], hi = w[1];
+#pragma unroll
+    for (int q = 1; q < 4; q++) { lo = wi == q ? w[q] : lo; hi = wi == q ? w[q + 1] : hi; }
+    if (wi == 4) { lo = w[4]; hi = 0; }
+    return (int)((u32)((((u64)hi << 32) | lo) >> sh) & 31u) - 16;
+  }
 }
 
 // Adds digit d of one GLV half: d in [-8, 8], `lam` selects beta*x, `neg` is the sign of that half.
@@ -219,26 +273,25 @@ ECGPU_HD void add_digit(JacK256& acc, const TabSlotK256* tab, int d, bool lam, b
 }
 
 // k * P for an affine, non-identity P; result in Jacobian coordinates on secp256k1.
+template <int WB>
 ECGPU_HD void mul_fast_jac(JacK256& acc, const FeK256& px, const FeK256& py, const u32* k, TabSlotK256* tab) {
+  constexpr int NPOS = K256Win<WB>::NPOS;
   GlvSplit s;
   glv_split(s, k);
   FeK256 zg;
-  table_build_globalz(tab, zg, px, py);
-  Radix16<4> d1, d2;
-  radix16_recode<4>(d1, s.k1);
-  radix16_recode<4>(d2, s.k2);
+  table_build_globalz<WB>(tab, zg, px, py);
+  u32 w1[K256_DW], w2[K256_DW];
+  recode_half<WB>(w1, s.k1);
+  recode_half<WB>(w2, s.k2);
   set_zero(acc.x); set_zero(acc.y); set_zero(acc.z);      // infinity
-  add_digit(acc, tab, (int)d1.top, false, s.neg1);
-  add_digit(acc, tab, (int)d2.top, true, s.neg2);
 #pragma unroll 1
-  for (int i = 31; i >= 0; i--) {
+  for (int i = NPOS - 1; i >= 0; i--) {
+    if (i != NPOS - 1) {
 #pragma unroll 1
-    for (int j = 0; j < 4; j++) jac_double(acc);
-    u32 w1 = d1.y[0], w2 = d2.y[0];
-#pragma unroll
-    for (int q = 1; q < 4; q++) { w1 = (i >> 3) == q ? d1.y[q] : w1; w2 = (i >> 3) == q ? d2.y[q] : w2; }
+      for (int j = 0; j < WB; j++) jac_double(acc);
+    }
 #pragma unroll 1
-    for (int h = 0; h < 2; h++) add_digit(acc, tab, radix16_digit(h ? w2 : w1, i & 7), h != 0, h ? s.neg2 : s.neg1);
+    for (int h = 0; h < 2; h++) add_digit(acc, tab, half_digit<WB>(h ? w2 : w1, i), h != 0, h ? s.neg2 : s.neg1);
   }
   mul(acc.z, acc.z, zg);     // back from the isomorphic curve
 }

@@ -14,8 +14,8 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
   // ECGPU_OPT_K256_WAVES (3 / 4) picks the occupancy variant; default chosen from measurements (profiles/r01_kbench_variants.txt)
   const int waves = c->opt[ECGPU_OPT_K256_WAVES] == 3 ? 3 : 4;
   const unsigned grid = ecgpu_grid_for(c, n, terms == 2 ? 4 : waves);
-  // per-lane table workspace: 1 KB per resident lane (268 MB at 4 waves/SIMD on 256 CUs), grow-only
-  const size_t ws_need = (size_t)grid * 256 * K256_TAB_SLOTS * sizeof(TabSlotK256) * terms;
+  // per-lane table workspace: 2 KB per resident lane for the single-term kernel (16 entries and their beta slots: 537 MB at 4 waves/SIMD), 2 x 1 KB for the two-term kernel
+  const size_t ws_need = (size_t)grid * 256 * sizeof(TabSlotK256) * (terms == 2 ? 2 * K256Win<4>::SLOTS : K256Win<K256_WB>::SLOTS);
   if (ws_need > c->tab_ws_cap) {
     if (c->tab_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->tab_ws)); c->tab_ws = nullptr; c->tab_ws_cap = 0; }
     HIPCHK(c, hipMalloc(&c->tab_ws, ws_need));

@@ -85,9 +85,11 @@ int ht_k256_to_affine(const uint8_t* pts, uint8_t* out, int n) {
 // ---- throughput schedule (mulfast_k256.hpp) -----------------------------------------------------
 #include "mulfast_k256.hpp"
 extern "C" {
-// points: affine x||y (zeros = identity) or, with proj != 0, homogeneous X||Y||Z; out: x||y||inf (65 B)
-int ht_k256_mul_fast(const uint8_t* pts, int proj, const uint8_t* ks, uint8_t* out, int n, int batch) {
-  TabSlotK256 tab[K256_TAB_SLOTS];
+}  // extern "C"
+// points: affine x||y (zeros = identity) or, with proj != 0, homogeneous X||Y||Z; out: x||y||inf (65 B); WB = window width (4 | 5)
+template <int WB>
+static int mul_fast_walk(const uint8_t* pts, int proj, const uint8_t* ks, uint8_t* out, int n, int batch) {
+  TabSlotK256 tab[K256Win<WB>::SLOTS];
   JacK256* res = (JacK256*)malloc(sizeof(JacK256) * batch);
   FeK256* pre = (FeK256*)malloc(sizeof(FeK256) * batch * 3);
   u32* inf = (u32*)malloc(sizeof(u32) * batch);
@@ -108,7 +110,7 @@ int ht_k256_mul_fast(const uint8_t* pts, int proj, const uint8_t* ks, uint8_t* o
       if (p_inf) { PtK256 g; k256::generator(g); px = g.x; py = g.y; k256::set_one(pz); }
       u32 k[8]; load_scalar(k, ks + 32 * (base + j));
       k256::scalar_reduce_once(k);
-      k256::mul_fast_jac(res[j], px, py, k, tab);
+      k256::mul_fast_jac<WB>(res[j], px, py, k, tab);
       k256::mul(res[j].z, res[j].z, pz);
       FeK256 zero; k256::set_zero(zero);
       k256::select(res[j].z, p_inf, zero, res[j].z);
@@ -121,6 +123,12 @@ int ht_k256_mul_fast(const uint8_t* pts, int proj, const uint8_t* ks, uint8_t* o
   }
   free(res); free(pre); free(inf);
   return 0;
+}
+extern "C" {
+// the product's window width (K256_WB) and, explicitly, both widths (the two-term kernel stays on 4 bits)
+int ht_k256_mul_fast(const uint8_t* pts, int proj, const uint8_t* ks, uint8_t* out, int n, int batch) { return mul_fast_walk<K256_WB>(pts, proj, ks, out, n, batch); }
+int ht_k256_mul_fast_w(int wb, const uint8_t* pts, int proj, const uint8_t* ks, uint8_t* out, int n, int batch) {
+  return wb == 4 ? mul_fast_walk<4>(pts, proj, ks, out, n, batch) : mul_fast_walk<5>(pts, proj, ks, out, n, batch);
 }
 // r = P + Q with P Jacobian (X||Y||Z, x = X/Z^2) and Q affine: out Jacobian X||Y||Z (canonical bytes)
 int ht_k256_jac_add_mixed(const uint8_t* p, const uint8_t* q, uint8_t* out, int n) {

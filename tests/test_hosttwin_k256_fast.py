@@ -54,18 +54,41 @@ def test_jacobian_primitives_including_exceptional_cases():
         assert jac_to_affine(X, Y, Z) == (None if a is None else M.affine_add(C, a, a)), i
 
 
+import pytest
+
+WB = 0          # window width the walks below use: 0 = the product's default (K256_WB), 4 | 5 explicitly
+
+
 def run_fast(pts_bytes, proj, ks, batch):
     n = len(ks)
     out = outbuf(65 * n)
-    assert lib().ht_k256_mul_fast(buf(pts_bytes), proj, buf(b"".join(M.i2b(C, k) for k in ks)), out, n, batch) == 0
+    sb = buf(b"".join(M.i2b(C, k) for k in ks))
+    if WB:
+        assert lib().ht_k256_mul_fast_w(WB, buf(pts_bytes), proj, sb, out, n, batch) == 0
+    else:
+        assert lib().ht_k256_mul_fast(buf(pts_bytes), proj, sb, out, n, batch) == 0
     o = bytes(out)
     return [o[65 * i:65 * i + 65] for i in range(n)]
 
 
+@pytest.fixture(params=[4, 5], autouse=True)
+def window_width(request):
+    """every test of this file runs on both window widths of the throughput schedule (mulfast_k256.hpp: 4 bits - the two-term kernel - and
+    5 bits - the single-term kernel since round 4)"""
+    global WB
+    WB = request.param
+    yield
+    WB = 0
+
+
 def test_mul_fast_affine_inputs_edges_and_random():
     rng = random.Random(32)
+    lam = M.K256_LAMBDA
     ks = [0, 1, 2, 3, 7, 8, 9, 15, 16, 17, N - 1, N - 2, N - 8, N - 9, (N - 1) // 2, (N + 1) // 2, 2**128 - 1, 2**128, 2**128 + 1,
-          M.K256_LAMBDA, M.K256_LAMBDA + 1, N - M.K256_LAMBDA, 2 * M.K256_LAMBDA % N, 16 * M.K256_LAMBDA % N]
+          lam, lam + 1, N - lam, 2 * lam % N, 16 * lam % N]
+    # the 5-bit recoding: digits -16 and 15, fields across the word boundaries of a half (bits 30-34, 60-64, 95-99, 125-129), in either half
+    ks += [31, 32, 33, 16 * 32**6, 31 * 32**6 + 15, 16 * 32**12, 31 * 32**19, 16 * 32**25 % N, (2**127 - 1), 31 * lam % N, 32 * lam % N, (16 * 32**6 * lam) % N,
+           (31 * 32**12 + (16 * 32**19) * lam) % N, (2**127 - 1) * lam % N]
     ks += [rng.randrange(N) for _ in range(70)] + [rng.randrange(2**32) for _ in range(10)]
     pts = [synth.point(C, i, seed=32) for i in range(len(ks))]
     pts[3] = None
