@@ -9,11 +9,11 @@ set -e
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 WORKLOAD=${WORKLOAD:-k256_varbase}
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 OUT=gpurun_out/prof_$WORKLOAD
 rm -rf "$OUT"; mkdir -p "$OUT"
 MATCH=${KERNEL_MATCH:-$(python3 -c "import bench; print(bench.WORKLOADS['$WORKLOAD']['pmc_match'])")}
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --workload $WORKLOAD"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-host-io --workload $WORKLOAD"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/trace.log" 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES" \
            "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY"; do
@@ -21,9 +21,10 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU S
   echo "[pmc] $grp"
   timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$tag" -- python3 $ARGS > "$OUT/pmc_$tag.log" 2>&1
 done
-# known read volume of the headline kernel: 2^24 units x (61.9 table blocks of 64 B + 96 B of input)
+# known read volume of the headline kernel: 2^24 units x (50.4 table blocks of 64 B - 52 digits x 31/32, 5-bit windows since round 4 - + 96 B of input)
+# (rounds 1-3, 4-bit windows: 61.9 blocks, 68073553920 bytes)
 KNOWN=${KNOWN_READ_BYTES:--}
-[ "$WORKLOAD" = k256_varbase ] && [ "$KNOWN" = "-" ] && KNOWN=68073553920
+[ "$WORKLOAD" = k256_varbase ] && [ "$KNOWN" = "-" ] && KNOWN=55700357120
 SUM=gpurun_out/pmc_summary_${ROUND}_${WORKLOAD}.json
 python3 tools/pmc_summarize.py "$OUT" "$MATCH" "$KNOWN" "$WORKLOAD" "${GIT_COMMIT:-unknown}" > "$SUM"
 cat "$SUM"

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, in two GPU calls (each well under the 20-minute limit):
-#   gpurun --timeout 1200 -- 'GIT_COMMIT=<sha> ROUND=r03 bash tools/round_evidence.sh A'
-#   gpurun --timeout 1200 -- 'GIT_COMMIT=<sha> ROUND=r03 bash tools/round_evidence.sh B'
+#   gpurun --timeout 1200 -- 'GIT_COMMIT=<sha> ROUND=r04 bash tools/round_evidence.sh A'
+#   gpurun --timeout 1200 -- 'GIT_COMMIT=<sha> ROUND=r04 bash tools/round_evidence.sh B'
 # A: kernel trace + PMC passes of the headline and of config 5, the constant-time counter evidence.
 # B: the same for configs 3 and 4, the MSM timeline and sizes, the secondary entry points, the forced-RCCL bench line.
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 O=gpurun_out/$ROUND
 mkdir -p "$O"
 part=${1:-A}
@@ -29,6 +29,8 @@ else
     timeout -k 10 200 python tools/gpu_quick.py p384 22 msm 2>&1 | grep msm | tail -1; } > "$O/msm_sizes.txt" 2>&1
   cat "$O/msm_sizes.txt"
   timeout -k 10 600 python tools/util_bench.py 20 > "$O/secondary_entry_points.txt" 2>&1; echo "util rc=$?"
+  { echo "# linear combinations of 3 .. 1024 terms (tools/lincomb_bench.py 22): shared doublings (csrc/straus.hpp) against the term-by-term form of rounds 1-3"; timeout -k 10 400 python tools/lincomb_bench.py 22 2>&1 | grep lincomb; } >> "$O/secondary_entry_points.txt"
+  timeout -k 10 300 python tools/host_pipeline_bench.py k256 24 4 msm > "$O/host_pipeline.txt" 2>&1; echo "hostpipe rc=$?"
   timeout -k 10 300 python bench.py --workload k256_msm --force-dist --steps 5 --no-cpu-baseline > "$O/bench_k256_msm_forcedist.json" 2> "$O/bench_k256_msm_forcedist.err"; echo "forcedist rc=$?"
   timeout -k 10 300 python tools/ct_varbase_bench.py 22 > "$O/ct_varbase_bench.txt" 2>&1; echo "ctbench rc=$?"
 fi
