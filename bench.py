@@ -83,7 +83,8 @@ WORK = {
     # copy) + table [P .. 16P] as a co-Z chain (doubling with update 2M+4S, 14 co-Z additions 4M+2S, 14M for the denominators = 72M+32S) + table to
     # affine through ONE inverted denominator and the chain's ratios (77M+15S) + (385S+14M)/16 + output normalise 6M+1S + (385S+14M)/16 (16 units per
     # lane and pass share the two inversions).  (Rounds 2-3: 4-bit windows, 96 x 4 doublings, 89 additions, 8-entry tables: 4 200 per unit.)
-    "p384_varbase": (1520 + (77 * 31 / 32 - 1) * 8 + 72 + 77 + 14 / 16 + 6 + 14 / 16, 1520 + (77 * 31 / 32 - 1) * 3 + 32 + 15 + 385 / 16 + 1 + 385 / 16),
+    # (the TABLE inversion is shared by the 2 units a wave draws at a time since the dynamic scheduling of round 4 - (385S+14M)/2 -, the output inversion by 16)
+    "p384_varbase": (1520 + (77 * 31 / 32 - 1) * 8 + 72 + 77 + 14 / 2 + 6 + 14 / 16, 1520 + (77 * 31 / 32 - 1) * 3 + 32 + 15 + 385 / 2 + 1 + 385 / 16),
     # bucket method with GLV halves, 7 windows of 18 / 19 bits at this size: 14 XYZZ mixed additions (8M+2S) per term;
     # per-term share of the endomorphism (1M), of the bucket pieces and of the bucket reduction (1.8 M buckets: XYZZ -> Jacobian
     # and two general additions 12M+4S each; 1.5 M pieces folded) ~ 9M + 3S

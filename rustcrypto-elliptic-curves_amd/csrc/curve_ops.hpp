@@ -17,6 +17,10 @@
 #define FB_BATCH (C::NW > 8 ? 16 : 64)
 #endif
 // occupancy target of the wide fixed-base kernel (A/B switch: 3 = 168 VGPRs, room for the gather prefetch ECGPU_FB_PREFETCH)
+// results per lane a wave of the wide fixed-base kernel draws at a time (sched.hpp): 16 results are about one variable-base unit's work
+#ifndef FB_CHUNK_UNITS
+#define FB_CHUNK_UNITS 16
+#endif
 #ifndef FB_WIDE_WAVES
 #define FB_WIDE_WAVES 4
 #endif
@@ -137,7 +141,7 @@ struct CurveOps {
       hipLaunchKernelGGL((fb::table_scalars_kernel<C, WB>), dim3(ecgpu_grid_for(c, cnt, 8)), dim3(256), 0, c->stream, (u32*)ks, e0, cnt);
       if constexpr (WB > 20)
         hipLaunchKernelGGL((fb::mul_wide_kernel<C, 20, FB_BATCH, 4>), dim3(ecgpu_grid_for(c, cnt, 4)), dim3(256), 0, c->stream, (const u32*)ks,
-                           (const AffEntry<C>*)c->fb20_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, cnt);
+                           (const AffEntry<C>*)c->fb20_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, cnt, WaveSched{nullptr, 0, 0, 0, 0});
       else
         hipLaunchKernelGGL((fb::mul_kernel<C, 16, 4>), dim3(ecgpu_grid_for(c, cnt, 4)), dim3(256), 0, c->stream, (const u32*)ks,
                            (const AffEntry<C>*)c->fb_table[C::ID], (u32*)xy, FMT_AFFINE, (uint8_t*)nullptr, cnt);
@@ -154,8 +158,11 @@ struct CurveOps {
   static int mul_gen_wide(ecgpu_ctx* c, void** slot, const u32* sc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
     int rc = ensure_fb_wide_table<WB>(c, slot);
     if (rc) return rc;
-    hipLaunchKernelGGL((fb::mul_wide_kernel<C, WB, FB_BATCH, FB_WIDE_WAVES>), dim3(ecgpu_grid_for(c, n, FB_WIDE_WAVES)), dim3(256), 0, c->stream, sc,
-                       (const AffEntry<C>*)*slot, out, out_fmt, out_inf, n);
+    unsigned long long* ctr = ecgpu_sched_counter(c);
+    if (!ctr) return ECGPU_ERR_RUNTIME;
+    const unsigned grid = ecgpu_grid_for(c, n, FB_WIDE_WAVES);
+    hipLaunchKernelGGL((fb::mul_wide_kernel<C, WB, FB_BATCH, FB_WIDE_WAVES>), dim3(grid), dim3(256), 0, c->stream, sc,
+                       (const AffEntry<C>*)*slot, out, out_fmt, out_inf, n, WaveSched{ctr, (unsigned long long)n, grid * 4u, (unsigned)FB_CHUNK_UNITS, 1u});
     HIPCHK(c, hipGetLastError());
     return 1;
   }

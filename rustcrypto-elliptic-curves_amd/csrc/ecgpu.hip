@@ -160,6 +160,7 @@ void ecgpu_destroy(ecgpu_ctx* c) {
   if (c->msm_ws) (void)hipFree(c->msm_ws);
   if (c->tab_ws) (void)hipFree(c->tab_ws);
   if (c->ecdsa_ws) (void)hipFree(c->ecdsa_ws);
+  if (c->sched_ctr) (void)hipFree(c->sched_ctr);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);

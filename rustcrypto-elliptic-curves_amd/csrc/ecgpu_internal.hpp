@@ -54,6 +54,9 @@ struct ecgpu_ctx {
   // MSM workspace (grow-only)
   void* msm_ws = nullptr;
   size_t msm_ws_cap = 0;
+  // work counters of the dynamically scheduled kernels (sched.hpp): a small ring, one 8-byte counter per launch, zeroed on the stream before it
+  unsigned long long* sched_ctr = nullptr;
+  unsigned sched_next = 0;
   // intermediate scalars / points of the ECDSA pipelines (grow-only)
   void* ecdsa_ws = nullptr;
   size_t ecdsa_ws_cap = 0;
@@ -75,6 +78,16 @@ static inline int ecgpu_set_err(ecgpu_ctx* c, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "%s: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
+// the counter of the next dynamically scheduled launch (sched.hpp), zeroed on the context's stream; nullptr on failure (error text set)
+static inline unsigned long long* ecgpu_sched_counter(ecgpu_ctx* c) {
+  constexpr unsigned RING = 64;
+  if (!c->sched_ctr) {
+    if (hipMalloc((void**)&c->sched_ctr, RING * sizeof(unsigned long long)) != hipSuccess) { ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "hipMalloc of the work counters failed"); return nullptr; }
+  }
+  unsigned long long* p = c->sched_ctr + (c->sched_next++ % RING);
+  if (hipMemsetAsync(p, 0, sizeof(unsigned long long), c->stream) != hipSuccess) { ecgpu_set_err(c, ECGPU_ERR_RUNTIME, "hipMemsetAsync of a work counter failed"); return nullptr; }
+  return p;
+}
 static inline unsigned ecgpu_grid_for(const ecgpu_ctx* c, size_t n, int per_cu) {
   size_t blocks = (n + 255) / 256;
   size_t cap = (size_t)c->num_cus * per_cu;

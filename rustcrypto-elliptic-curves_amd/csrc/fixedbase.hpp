@@ -14,6 +14,7 @@
 #include "jacobian.hpp"
 #include "fixedbase_ct.hpp"
 #include "kernels.hpp"
+#include "sched.hpp"
 #include "msm.hpp"                // XYZZ accumulators (8M + 2S per mixed addition)
 
 namespace ecgpu {
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(256) table_affine_kernel(const Jac<C>* tmp, Af
 // addition saves is saved once per addition).  Same output formats as jac::store_batch_affine.
 template <class C>
 ECGPU_HD void store_batch_affine_xyzz(const msm::Xyzz<C>* res, typename C::Fe* pre, int cnt, size_t base, size_t stride, u32* out, int out_fmt,
-                                      uint8_t* out_inf) {
+                                      uint8_t* out_inf, const size_t* idx = nullptr) {
   using Fe = typename C::Fe;
   constexpr int NW = C::NW;
   Fe acc; C::fe_one(acc);
@@ -90,7 +91,7 @@ ECGPU_HD void store_batch_affine_xyzz(const msm::Xyzz<C>* res, typename C::Fe* p
   C::fe_inv(ai, acc);
 #pragma unroll 1
   for (int j = cnt - 1; j >= 0; j--) {
-    const size_t i = base + (size_t)j * stride;
+    const size_t i = idx ? idx[j] : base + (size_t)j * stride;
     Fe one, zero, wi, t, x, y;
     C::fe_one(one); C::fe_zero(zero);
     const bool zr = C::fe_is_zero(res[j].zz);
@@ -126,8 +127,9 @@ struct FbAcc {
   static ECGPU_HD void set_infinity(Pt& p) { msm::xyzz_set_infinity<C>(p); }
   static ECGPU_HD void add_mixed(Pt& p, const typename C::Fe& x, const typename C::Fe& y) { msm::xyzz_add_mixed<C>(p, x, y); }
   static ECGPU_HD void add_affine(Pt& p, const typename C::Fe& x, const typename C::Fe& y) { msm::xyzz_add_affine<C>(p, x, y); }
-  static ECGPU_HD void store(const Pt* res, typename C::Fe* pre, int cnt, size_t base, size_t stride, u32* out, int out_fmt, uint8_t* out_inf) {
-    store_batch_affine_xyzz<C>(res, pre, cnt, base, stride, out, out_fmt, out_inf);
+  static ECGPU_HD void store(const Pt* res, typename C::Fe* pre, int cnt, size_t base, size_t stride, u32* out, int out_fmt, uint8_t* out_inf,
+                             const size_t* idx = nullptr) {
+    store_batch_affine_xyzz<C>(res, pre, cnt, base, stride, out, out_fmt, out_inf, idx);
   }
 };
 template <class C>
@@ -136,8 +138,9 @@ struct FbAcc<C, false> {
   static ECGPU_HD void set_infinity(Pt& p) { jac::set_infinity<C>(p); }
   static ECGPU_HD void add_mixed(Pt& p, const typename C::Fe& x, const typename C::Fe& y) { jac::add_mixed<C>(p, x, y); }
   static ECGPU_HD void add_affine(Pt& p, const typename C::Fe& x, const typename C::Fe& y) { jac::add_affine<C>(p, x, y); }
-  static ECGPU_HD void store(const Pt* res, typename C::Fe* pre, int cnt, size_t base, size_t stride, u32* out, int out_fmt, uint8_t* out_inf) {
-    jac::store_batch_affine<C>(res, pre, cnt, base, stride, out, out_fmt, out_inf);
+  static ECGPU_HD void store(const Pt* res, typename C::Fe* pre, int cnt, size_t base, size_t stride, u32* out, int out_fmt, uint8_t* out_inf,
+                             const size_t* idx = nullptr) {
+    jac::store_batch_affine<C>(res, pre, cnt, base, stride, out, out_fmt, out_inf, idx);
   }
 };
 
@@ -253,16 +256,30 @@ __global__ void __launch_bounds__(256) table_scalars_kernel(u32* out, size_t fir
 // The accumulator is FbAcc<C>: XYZZ on the 256-bit curves (round 3; Jacobian before), Jacobian on P-384.
 template <class C, int WB, int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars, const AffEntry<C>* table, u32* out, int out_fmt,
-                                                           uint8_t* out_inf, size_t n) {
+                                                           uint8_t* out_inf, size_t n_all, WaveSched sched) {
   constexpr int NW = C::NW;
   typename FbAcc<C>::Pt res[BATCH];
   typename C::Fe pre[BATCH];
-  const size_t T = (size_t)gridDim.x * blockDim.x;
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (size_t base = tid; base < n; base += T * BATCH) {
-    int cnt = 0;
+  size_t idx[BATCH];                 // global index of every buffered result
+  // Every wave draws small chunks of 64 x u consecutive scalars (sched.hpp), keeps the results in res[] across chunks and flushes them with one
+  // shared inversion when the buffer is full or the work has run out.  A null counter = the static grid stride (the table builds use it).
+  const bool dynamic = sched.counter != nullptr;
+  const size_t T = dynamic ? (size_t)64 : (size_t)gridDim.x * blockDim.x;
+  size_t base = dynamic ? 0 : (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = n_all;
+  int cnt = 0, slots = 0;            // results buffered by this lane; per-lane units drawn since the last flush (wave-uniform)
+  for (;;) {
+    int units = BATCH;
+    bool more = true;
+    if (dynamic) {
+      size_t lo;
+      more = wave_next_chunk(sched, lo, n);
+      base = lo + (threadIdx.x & 63u);
+      units = more ? (int)((n - lo + 63) / 64) : 0;
+    } else if (base >= n) {
+      break;
+    }
 #pragma unroll 1
-    for (int b = 0; b < BATCH; b++) {
+    for (int b = 0; b < units; b++) {
       const size_t i = base + (size_t)b * T;
       if (i >= n) break;
       u32 k[NW], ord[NW], t[NW];
@@ -331,10 +348,18 @@ __global__ void __launch_bounds__(256, WAVES) mul_wide_kernel(const u32* scalars
           }
         }
       }
-      res[b] = acc;
-      cnt = b + 1;
+      res[cnt] = acc;
+      idx[cnt] = i;
+      cnt++;
     }
-    FbAcc<C>::store(res, pre, cnt, base, T, out, out_fmt, out_inf);
+    slots += units;
+    if (!dynamic || !more || slots + (int)sched.chunk_units > BATCH) {
+      if (cnt) FbAcc<C>::store(res, pre, cnt, 0, 0, out, out_fmt, out_inf, idx);
+      cnt = 0;
+      slots = 0;
+    }
+    if (dynamic && !more) break;
+    if (!dynamic) base += T * BATCH;
   }
 }
 

@@ -246,9 +246,10 @@ ECGPU_HD void batch_to_affine(typename C::Fe* ax, typename C::Fe* ay, u32* inf, 
 // base + j * stride - go to affine with ONE inversion and are written in the caller's format: affine x || y
 // (+ infinity byte, zeros for the identity) or the homogeneous representative (x : y : 1), identity (0 : 1 : 0).
 // J is any {x, y, z} of C::Fe; `pre` is scratch for cnt field elements.
+// `idx` (optional): the global index of element j, for callers whose results do not sit at base + j * stride (the dynamically scheduled kernels)
 template <class C, class J>
 ECGPU_HD void store_batch_affine(const J* res, typename C::Fe* pre, int cnt, size_t base, size_t stride, u32* out, int out_fmt,
-                                 uint8_t* out_inf) {
+                                 uint8_t* out_inf, const size_t* idx = nullptr) {
   using Fe = typename C::Fe;
   constexpr int NW = C::NW;
   Fe acc; C::fe_one(acc);
@@ -263,7 +264,7 @@ ECGPU_HD void store_batch_affine(const J* res, typename C::Fe* pre, int cnt, siz
   C::fe_inv(ai, acc);
 #pragma unroll 1
   for (int j = cnt - 1; j >= 0; j--) {
-    const size_t i = base + (size_t)j * stride;
+    const size_t i = idx ? idx[j] : base + (size_t)j * stride;
     Fe z = res[j].z, one, zero, zi, t, x, y;
     C::fe_one(one); C::fe_zero(zero);
     const bool zr = C::fe_is_zero(z);

@@ -9,6 +9,7 @@
 #include "traits.hpp"
 #include "mulfast_k256.hpp"
 #include "jacobian.hpp"
+#include "sched.hpp"
 
 namespace ecgpu {
 
@@ -409,16 +410,25 @@ __global__ void __launch_bounds__(256, WAVES) k256_lincomb2_fast_kernel(const u3
 
 template <int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k256_mul_fast_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out,
-                                                            int out_fmt, uint8_t* out_inf, size_t n, TabSlotK256* table_ws) {
-  // this lane's table: 16 slots x 64 B, contiguous, in the launch's global workspace (gridDim * 256 lanes)
+                                                            int out_fmt, uint8_t* out_inf, size_t n, TabSlotK256* table_ws, WaveSched sched) {
+  // this lane's table: 32 slots x 64 B, contiguous, in the launch's global workspace (gridDim * 256 lanes)
   constexpr int WB = K256_WB;
   TabSlotK256* tab = table_ws + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * K256Win<WB>::SLOTS;
+#ifdef K256_BLOCK_TIMES              // DIAGNOSTIC build: every workgroup records when it started and ended and where it ran, behind the table workspace
+  unsigned long long* blk_times = (unsigned long long*)(table_ws + (size_t)gridDim.x * blockDim.x * K256Win<WB>::SLOTS) + 4 * (size_t)blockIdx.x;
+  if (threadIdx.x == 0) {
+    blk_times[0] = wall_clock64();
+    blk_times[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID: wave, simd, pipe, cu, sh, se
+    blk_times[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // XCC_ID
+  }
+#endif
   K256FastPrep prep;
   JacK256 res[BATCH];
   FeK256 pre[BATCH];
+  const int pw = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * 8;
+#ifdef ECGPU_STATIC_GRID_STRIDE      // A/B switch: the static assignment of rounds 1-3 (every lane the same number of units, grid stride)
   const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int pw = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * 8;
   for (size_t base = tid; base < n; base += T * BATCH) {
     int cnt = 0;
 #pragma unroll 1
@@ -431,6 +441,37 @@ __global__ void __launch_bounds__(256, WAVES) k256_mul_fast_kernel(const u32* sc
     }
     k256_fast_finish(res, pre, cnt, base, T, out, out_fmt, out_inf);
   }
+#else
+  // Every wave draws small chunks of 64 x u consecutive units (sched.hpp): lane l takes units lo + l, lo + l + 64, ..; the results stay in res[]
+  // across chunks and are flushed - ONE shared inversion - when the buffer is full or the work has run out.
+  size_t idx[BATCH];                 // global index of every buffered result
+  int cnt = 0, slots = 0;            // results buffered by this lane; per-lane units drawn since the last flush (wave-uniform)
+  for (;;) {
+    size_t lo, hi;
+    const bool more = wave_next_chunk(sched, lo, hi);
+    const int units = more ? (int)((hi - lo + 63) / 64) : 0;
+#pragma unroll 1
+    for (int j = 0; j < units; j++) {
+      const size_t i = lo + (threadIdx.x & 63u) + (size_t)j * 64;
+      if (i >= hi) break;
+      k256_fast_prep<WB>(&prep, tab, scalars + i * 8, points + i * pw, pt_fmt);
+      k256_fast_loop<WB>(&res[cnt], &prep, tab);
+      idx[cnt] = i;
+      cnt++;
+    }
+    slots += units;
+    if (!more || slots + (int)sched.chunk_units > BATCH) {
+      if (cnt) jac::store_batch_affine<CurveK256>(res, pre, cnt, 0, 0, out, out_fmt, out_inf, idx);
+      cnt = 0;
+      slots = 0;
+    }
+    if (!more) break;
+  }
+#endif
+#ifdef K256_BLOCK_TIMES
+  __syncthreads();
+  if (threadIdx.x == 0) blk_times[1] = wall_clock64();
+#endif
 }
 
 template <class C>

@@ -1,6 +1,10 @@
 // secp256k1 kernels and launchers (one translation unit per curve: the library builds in parallel).
 #include "curve_ops.hpp"
 using namespace ecgpu;
+// per-lane units a wave draws at a time from the work counter (sched.hpp); the results of up to K256_FAST_BATCH units share one inversion
+#ifndef K256_CHUNK_UNITS
+#define K256_CHUNK_UNITS 2
+#endif
 #ifndef K256_FAST_BATCH
 #define K256_FAST_BATCH 32   // results per lane that share one inversion in the variable-base kernel (16: -0.4 %)
 #endif
@@ -13,9 +17,17 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
   if (!pts) return 0;
   // ECGPU_OPT_K256_WAVES (3 / 4) picks the occupancy variant; default chosen from measurements (profiles/r01_kbench_variants.txt)
   const int waves = c->opt[ECGPU_OPT_K256_WAVES] == 3 ? 3 : 4;
+#ifdef K256_GRID_PER_CU            // A/B switch: workgroups per CU of the single-term kernel's launch, whatever its occupancy target
+  const unsigned grid = ecgpu_grid_for(c, n, terms == 2 ? 4 : K256_GRID_PER_CU);
+#else
   const unsigned grid = ecgpu_grid_for(c, n, terms == 2 ? 4 : waves);
+#endif
   // per-lane table workspace: 2 KB per resident lane for the single-term kernel (16 entries and their beta slots: 537 MB at 4 waves/SIMD), 2 x 1 KB for the two-term kernel
+#ifdef K256_BLOCK_TIMES
+  const size_t ws_need = (size_t)grid * 256 * sizeof(TabSlotK256) * (terms == 2 ? 2 * K256Win<4>::SLOTS : K256Win<K256_WB>::SLOTS) + (size_t)grid * 32 + 16;
+#else
   const size_t ws_need = (size_t)grid * 256 * sizeof(TabSlotK256) * (terms == 2 ? 2 * K256Win<4>::SLOTS : K256Win<K256_WB>::SLOTS);
+#endif
   if (ws_need > c->tab_ws_cap) {
     if (c->tab_ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->tab_ws)); c->tab_ws = nullptr; c->tab_ws_cap = 0; }
     HIPCHK(c, hipMalloc(&c->tab_ws, ws_need));
@@ -27,10 +39,13 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
     HIPCHK(c, hipGetLastError());
     return 1;
   }
+  unsigned long long* ctr = ecgpu_sched_counter(c);
+  if (!ctr) return ECGPU_ERR_RUNTIME;
+  const WaveSched sched{ctr, (unsigned long long)n, grid * 4u, (unsigned)K256_CHUNK_UNITS, 1u};
   if (waves == 3)
-    hipLaunchKernelGGL((k256_mul_fast_kernel<K256_FAST_BATCH, 3>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
+    hipLaunchKernelGGL((k256_mul_fast_kernel<K256_FAST_BATCH, 3>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws, sched);
   else
-    hipLaunchKernelGGL((k256_mul_fast_kernel<K256_FAST_BATCH, 4>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
+    hipLaunchKernelGGL((k256_mul_fast_kernel<K256_FAST_BATCH, 4>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws, sched);
   HIPCHK(c, hipGetLastError());
   return 1;
 }

@@ -47,9 +47,12 @@ template <class C, int WB> constexpr int digit_words() { return WB == 4 ? C::NW 
 // Measured against Jacobian tables with general additions: +8.5 % for P-384 (16.6 against 15.3 M/s at 2^21), +3.7 % for
 // P-256 (53.2 against 51.3; in round 1, with a square-and-multiply inversion of 384 multiplications instead of the
 // 267-multiplication chain, the extra pass over the tables cost P-256 more than the cheaper additions saved).
+// `res_ext` / `idx_ext` / `cnt_ext` (optional, all or none): instead of converting its results to affine and storing them, the pass APPENDS them
+// (Jacobian) with their global indices to the caller's per-lane buffer - the dynamically scheduled kernel draws small passes (the TABLE inversion
+// is shared by the units of one pass) and flushes the buffer with one OUTPUT inversion whenever it is full (varbase.hpp, sched.hpp).
 template <class C, int BATCH, int NT = 1, int WB = 4>
 ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf, size_t n, size_t base,
-                        size_t T, LaneWs<C, BATCH, WB>& ws, const DigitMem& dm) {
+                        size_t T, LaneWs<C, BATCH, WB>& ws, const DigitMem& dm, Jac<C>* res_ext = nullptr, size_t* idx_ext = nullptr, int* cnt_ext = nullptr) {
   static_assert(BATCH % NT == 0 && BATCH <= 32, "table slots per pass");
   static_assert(WB == 4 || WB == 5, "window width");
   constexpr int NW = C::NW;
@@ -243,9 +246,10 @@ ECGPU_HD void lane_pass(const u32* scalars, const u32* points, int pt_fmt, u32* 
         }
       }
     }
-    res[b] = acc;
+    if (res_ext) { res_ext[*cnt_ext] = acc; idx_ext[*cnt_ext] = i; (*cnt_ext)++; }
+    else res[b] = acc;
   }
-  jac::store_batch_affine<C>(res, pre, cnt, base, T, out, out_fmt, out_inf);
+  if (!res_ext) jac::store_batch_affine<C>(res, pre, cnt, base, T, out, out_fmt, out_inf);
 }
 
 }  // namespace vb
