@@ -363,21 +363,24 @@ __device__ __forceinline__ void k256_fast_rescale(TabSlotK256* tab, const FeK256
 
 template <int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k256_lincomb2_fast_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out,
-                                                                 int out_fmt, uint8_t* out_inf, size_t n, TabSlotK256* table_ws) {
+                                                                 int out_fmt, uint8_t* out_inf, size_t n, TabSlotK256* table_ws, WaveSched sched) {
   constexpr int WB = 4, SLOTS = K256Win<WB>::SLOTS, NPOS = K256Win<WB>::NPOS;       // 4-bit windows: this kernel rescales both tables entry by entry (5 bits: -6 %)
   TabSlotK256* tab = table_ws + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (2 * SLOTS);
   K256FastPrep prep[2];
   JacK256 res[BATCH];
   FeK256 pre[BATCH];
-  const size_t T = (size_t)gridDim.x * blockDim.x;
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int pw = (pt_fmt == FMT_PROJECTIVE ? 3 : 2) * 8;
-  for (size_t base = tid; base < n; base += T * BATCH) {
-    int cnt = 0;
+  // dynamic work distribution (sched.hpp): small chunks drawn per wave, results buffered across chunks, one shared inversion per full buffer
+  size_t idx[BATCH];
+  int cnt = 0, slots = 0;
+  for (;;) {
+    size_t lo, hi;
+    const bool more = wave_next_chunk(sched, lo, hi);
+    const int units = more ? (int)((hi - lo + 63) / 64) : 0;
 #pragma unroll 1
-    for (int j = 0; j < BATCH; j++) {
-      const size_t i = base + (size_t)j * T;
-      if (i >= n) break;
+    for (int j = 0; j < units; j++) {
+      const size_t i = lo + (threadIdx.x & 63u) + (size_t)j * 64;
+      if (i >= hi) break;
 #pragma unroll 1
       for (int t = 0; t < 2; t++) k256_fast_prep<WB>(&prep[t], tab + t * SLOTS, scalars + (2 * i + t) * 8, points + (2 * i + t) * pw, pt_fmt);
 #pragma unroll 1
@@ -401,10 +404,17 @@ __global__ void __launch_bounds__(256, WAVES) k256_lincomb2_fast_kernel(const u3
       FeK256 zf;
       k256::mul(zf, prep[0].zfix, prep[1].zfix);
       k256::mul(acc.z, acc.z, zf);
-      res[j] = acc;
-      cnt = j + 1;
+      res[cnt] = acc;
+      idx[cnt] = i;
+      cnt++;
     }
-    k256_fast_finish(res, pre, cnt, base, T, out, out_fmt, out_inf);
+    slots += units;
+    if (!more || slots + (int)sched.chunk_units > BATCH) {
+      if (cnt) jac::store_batch_affine<CurveK256>(res, pre, cnt, 0, 0, out, out_fmt, out_inf, idx);
+      cnt = 0;
+      slots = 0;
+    }
+    if (!more) break;
   }
 }
 

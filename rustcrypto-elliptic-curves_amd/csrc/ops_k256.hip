@@ -34,13 +34,14 @@ int CurveOps<CurveK256>::lincomb_fast(ecgpu_ctx* c, const u32* sc, const u32* pt
     c->tab_ws_cap = ws_need;
   }
   TabSlotK256* ws = (TabSlotK256*)c->tab_ws;
+  unsigned long long* ctr = ecgpu_sched_counter(c);
+  if (!ctr) return ECGPU_ERR_RUNTIME;
   if (terms == 2) {
-    hipLaunchKernelGGL((k256_lincomb2_fast_kernel<16, 4>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws);
+    hipLaunchKernelGGL((k256_lincomb2_fast_kernel<16, 4>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws,
+                       WaveSched{ctr, (unsigned long long)n, grid * 4u, 1u, 1u});
     HIPCHK(c, hipGetLastError());
     return 1;
   }
-  unsigned long long* ctr = ecgpu_sched_counter(c);
-  if (!ctr) return ECGPU_ERR_RUNTIME;
   const WaveSched sched{ctr, (unsigned long long)n, grid * 4u, (unsigned)K256_CHUNK_UNITS, 1u};
   if (waves == 3)
     hipLaunchKernelGGL((k256_mul_fast_kernel<K256_FAST_BATCH, 3>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n, ws, sched);

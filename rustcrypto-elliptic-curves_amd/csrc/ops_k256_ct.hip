@@ -46,7 +46,12 @@ static int tab_reserve(ecgpu_ctx* c, size_t need) {
 size_t ecgpuint_k256_ct_pass_units(const ecgpu_ctx* c) { return (size_t)c->num_cus * K256_CT_WAVES * 256 * K256_CT_BATCH; }
 
 int ecgpuint_k256_mul_ct(ecgpu_ctx* c, const uint32_t* sc, const uint32_t* pts, int pt_fmt, uint32_t* out, int out_fmt, uint8_t* out_inf, size_t n) {
-  const dim3 grid(ecgpu_grid_for(c, n, K256_CT_WAVES));
+  // K256_CT_GRID_MULT (round 4): more workgroups than the chip holds, STATIC work per workgroup - the hardware hands the waiting workgroups out as the
+  // favoured waves of a SIMD leave (sched.hpp explains the imbalance; the constant-time kernels do not draw their work from a counter)
+#ifndef K256_CT_GRID_MULT
+#define K256_CT_GRID_MULT 4      // ECDH kernel, 2^22 units: 1 / 2 / 4 / 8 = 42.6 / 39.8 / 39.0 / 38.9 ms (profiles/r04_ab_measurements.txt, set seven)
+#endif
+  const dim3 grid(ecgpu_grid_for(c, n, K256_CT_WAVES * K256_CT_GRID_MULT));
   int rc = tab_reserve(c, (size_t)grid.x * 256 * vbct::k256_lane_chunks<K256_CT_BATCH>() * sizeof(vbct::Chunk));
   if (rc) return rc;
   hipLaunchKernelGGL((k256_mul_ct_kernel<K256_CT_BATCH, K256_CT_WAVES>), grid, dim3(256), 0, c->stream, sc, pts, pt_fmt, out, out_fmt, out_inf, n,
