@@ -13,6 +13,9 @@
 // the inversion's share is large: measured at 2^24 scalars, batch 16 / 32 / 64: p256 0.96 / 1.03 / 1.06, k256 1.19 /
 // 1.24 / 1.25 x 10^9 per second; p384 (2^22) 282 / 280 / 279 x 10^6 (its results are 144 bytes each in the private
 // segment), hence 16 there.
+#ifndef ECGPU_REF_GRID_MULT
+#define ECGPU_REF_GRID_MULT 4
+#endif
 #ifndef FB_BATCH
 #define FB_BATCH (C::NW > 8 ? 16 : 64)
 #endif
@@ -231,7 +234,9 @@ struct CurveOps {
       if (rc < 0) return rc;
       if (rc == 1) return 0;
     }
-    const unsigned g = ecgpu_grid_for(c, n, 4);
+    // (the reference-schedule kernels walk their units one at a time with a grid stride: four times the workgroups the chip holds, so that the hardware
+    // hands the waiting ones out as the favoured waves of a SIMD leave - sched.hpp)
+    const unsigned g = ecgpu_grid_for(c, n, 4 * ECGPU_REF_GRID_MULT);
     if (!pts && terms != 1) return ecgpu_set_err(c, ECGPU_ERR_ARG, "generator multiplication takes one term");
     if (terms > 2 && terms <= 1024 && !(flags & ECGPU_EXACT_REFERENCE)) {
       if (c->opt[ECGPU_OPT_LINCOMB_TERM_BY_TERM]) {

@@ -14,6 +14,9 @@
 #include "varbase_ct_k256.hpp"
 using namespace ecgpu;
 
+#ifndef ECGPU_REF_GRID_MULT
+#define ECGPU_REF_GRID_MULT 4
+#endif
 #ifndef K256_CT_BATCH
 #define K256_CT_BATCH 16
 #endif
@@ -70,7 +73,9 @@ int ecgpuint_k256_mul_gen_ct(ecgpu_ctx* c, const uint32_t* sc, const void* table
 int ecgpuint_k256_reference(ecgpu_ctx* c, const uint32_t* sc, const uint32_t* pts, int pt_fmt, size_t terms, const void* gen_table, uint32_t* out, int out_fmt,
                             uint8_t* out_inf, size_t n) {
   using C = CurveK256;
-  const unsigned g = ecgpu_grid_for(c, n, 4);
+  // four times the workgroups the chip holds (the kernels walk their units with a grid stride, one at a time: no per-lane batch to shrink): the hardware
+  // hands the waiting workgroups out as the favoured waves of a SIMD leave (sched.hpp)
+  const unsigned g = ecgpu_grid_for(c, n, 4 * ECGPU_REF_GRID_MULT);
   if (!pts) {
     hipLaunchKernelGGL((mul_gen_ref_kernel<C>), dim3(g), dim3(256), 0, c->stream, sc, (const PtK256*)gen_table, out, out_fmt, out_inf, n);
   } else if (terms == 1) {
