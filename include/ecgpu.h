@@ -113,7 +113,10 @@ enum {
    * reference's GLV split and recoding on Jacobian formulas over one per-lane common-Z table (one masked scan per window serves both
    * halves, beta x multiplied in); the bounds of the split keep every addition off the exceptional cases (the file has the
    * argument: the accumulator's two coordinates stay below the GLV lattice's shortest vector) - 1.5x the reference schedule.
-   * Staged host copies of the scalars are cleared as with ECGPU_EXACT_REFERENCE. */
+   * Staged host copies of the scalars are cleared as with ECGPU_EXACT_REFERENCE.
+   * Precondition, as for the reference's types: the points are points of the curve.  ecgpu_mul_batch does not validate them (ecgpu_validate_points /
+   * ecgpu_ecdh_batch do); for a point that is NOT on the curve the element's own result is unspecified, but it cannot disturb any other element of the
+   * batch (a zero denominator is flagged and kept out of the shared inversions), and the instruction stream does not depend on it. */
   ECGPU_SECRET_SCALARS = 8u
 };
 
