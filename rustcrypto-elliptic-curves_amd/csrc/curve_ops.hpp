@@ -290,8 +290,10 @@ struct CurveOps {
     if (rc) return rc;
     if ((rc = ecdsa_reserve(c, al256(items * 3 * C::NW * sizeof(u32))))) return rc;
     u32* partial = (u32*)c->ecdsa_ws;
+    unsigned long long* ctr = ecgpu_sched_counter(c);
+    if (!ctr) return ECGPU_ERR_RUNTIME;
     hipLaunchKernelGGL((straus::lincomb_kernel<C, WAVES>), dim3(grid), dim3(256), 0, c->stream, sc, pts, pt_fmt, (int)terms, g, gpc, items,
-                       (straus::LaneWs<C>*)c->tab_ws, partial);
+                       (straus::LaneWs<C>*)c->tab_ws, partial, WaveSched{ctr, (unsigned long long)items, grid * 4u, (unsigned)upp, 0u});
     hipLaunchKernelGGL((straus::fold_kernel<C>), dim3(ecgpu_grid_for(c, (n + 15) / 16, 8)), dim3(256), 0, c->stream, (const u32*)partial, gpc, out, out_fmt, out_inf, n);
     HIPCHK(c, hipGetLastError());
     return 0;

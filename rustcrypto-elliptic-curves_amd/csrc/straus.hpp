@@ -22,6 +22,9 @@
 #pragma once
 #include "jacobian.hpp"
 #include "mulfast_k256.hpp"
+#ifdef __HIPCC__
+#include "sched.hpp"
+#endif
 
 namespace ecgpu {
 namespace straus {
@@ -276,12 +279,12 @@ ECGPU_HD void fold_pass(const u32* partial, int gpc, u32* out, int out_fmt, uint
 #ifdef __HIPCC__
 template <class C, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) lincomb_kernel(const u32* scalars, const u32* points, int pt_fmt, int terms, int g, int gpc, size_t items, LaneWs<C>* ws_all,
-                                                             u32* partial) {
+                                                             u32* partial, WaveSched sched) {
   LaneWs<C>& ws = ws_all[(size_t)blockIdx.x * blockDim.x + threadIdx.x];
-  const size_t T = (size_t)gridDim.x * blockDim.x;
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t upp = (size_t)(SLOTS / g);
-  for (size_t base = tid; base < items; base += T * upp) lane_pass<C>(scalars, points, pt_fmt, terms, g, gpc, items, base, T, ws, partial);
+  // every wave draws whole passes (SLOTS / g work items per lane: their tables share one inversion) from one counter (sched.hpp): with more passes than
+  // resident lanes the favoured waves of a SIMD take more of them instead of idling at the end
+  size_t lo, hi;
+  while (wave_next_chunk(sched, lo, hi)) lane_pass<C>(scalars, points, pt_fmt, terms, g, gpc, hi, lo + (threadIdx.x & 63u), 64, ws, partial);
 }
 template <class C>
 __global__ void __launch_bounds__(256) fold_kernel(const u32* partial, int gpc, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
