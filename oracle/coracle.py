@@ -12,7 +12,7 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(HERE, "libecoracle.so")
+        path = os.environ.get("ECGPU_ORACLE_LIB") or os.path.join(HERE, "libecoracle.so")      # override: a sanitizer build (tools/hosttwin_sanitize.sh)
         if not os.path.exists(path):
             subprocess.run(["make", "-s", "-C", HERE], check=True)
         L = ctypes.CDLL(path)

@@ -10,6 +10,10 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
+        override = os.environ.get("ECGPU_HOSTTWIN_LIB")          # a sanitizer build of the same sources (tools/hosttwin_sanitize.sh)
+        if override:
+            _LIB = ctypes.CDLL(override)
+            return _LIB
         d = os.path.join(HERE, "hosttwin")
         subprocess.run(["make", "-s", "-C", d], check=True)
         _LIB = ctypes.CDLL(os.path.join(d, "libechosttwin.so"))
