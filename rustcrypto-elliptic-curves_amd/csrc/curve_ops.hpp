@@ -34,6 +34,10 @@
 #ifndef FBCT_WAVES
 #define FBCT_WAVES(C) (C::NW > 8 ? 3 : 4)
 #endif
+// most workgroups launched per resident one by the constant-time fixed-base kernel (ecgpu_grid_oversubscribed; profiles/r04_ab_measurements.txt, set nine)
+#ifndef FBCT_GRID_MULT
+#define FBCT_GRID_MULT 4
+#endif
 
 namespace ecgpu {
 
@@ -207,7 +211,7 @@ struct CurveOps {
       return ecgpuint_k256_mul_gen_ct(c, sc, c->fbct_table[C::ID], out, out_fmt, out_inf, n);
     } else {
       constexpr int WAVES = FBCT_WAVES(C);
-      hipLaunchKernelGGL((fb::mul_ct_kernel<C, 8, WAVES>), dim3(ecgpu_grid_for(c, n, WAVES)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)c->fbct_table[C::ID], out,
+      hipLaunchKernelGGL((fb::mul_ct_kernel<C, 8, WAVES>), dim3(ecgpu_grid_oversubscribed(c, n, WAVES, 8, FBCT_GRID_MULT)), dim3(256), 0, c->stream, sc, (const AffEntry<C>*)c->fbct_table[C::ID], out,
                          out_fmt, out_inf, n);
       HIPCHK(c, hipGetLastError());
       return 0;

@@ -26,6 +26,9 @@ using namespace ecgpu;
 #ifndef K256_FBCT_WAVES
 #define K256_FBCT_WAVES 4      // curve_ops.hpp FBCT_WAVES for 8-word fields
 #endif
+#ifndef FBCT_GRID_MULT
+#define FBCT_GRID_MULT 4        // as in curve_ops.hpp
+#endif
 
 template <int BATCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k256_mul_ct_kernel(const u32* scalars, const u32* points, int pt_fmt, u32* out, int out_fmt, uint8_t* out_inf,
@@ -64,7 +67,7 @@ int ecgpuint_k256_mul_ct(ecgpu_ctx* c, const uint32_t* sc, const uint32_t* pts, 
 }
 
 int ecgpuint_k256_mul_gen_ct(ecgpu_ctx* c, const uint32_t* sc, const void* table, uint32_t* out, int out_fmt, uint8_t* out_inf, size_t n) {
-  hipLaunchKernelGGL((fb::mul_ct_kernel<CurveK256, 8, K256_FBCT_WAVES>), dim3(ecgpu_grid_for(c, n, K256_FBCT_WAVES)), dim3(256), 0, c->stream, sc,
+  hipLaunchKernelGGL((fb::mul_ct_kernel<CurveK256, 8, K256_FBCT_WAVES>), dim3(ecgpu_grid_oversubscribed(c, n, K256_FBCT_WAVES, 8, FBCT_GRID_MULT)), dim3(256), 0, c->stream, sc,
                      (const AffEntry<CurveK256>*)table, out, out_fmt, out_inf, n);
   HIPCHK(c, hipGetLastError());
   return 0;

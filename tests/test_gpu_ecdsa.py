@@ -173,6 +173,45 @@ def test_large_batch_all_valid_and_sparse_invalid(ctx):
     ctx.set_stream(0)
 
 
+@pytest.mark.parametrize("cn,n", [("k256", (1 << 22) + 4321), ("p256", 1 << 22), ("k256", 1 << 23), ("p384", (3 << 20) + 77)])
+def test_signing_constant_time_grid_sizes(ctx, cn, n):
+    """The constant-time fixed-base kernel launches up to four times the resident workgroups once every lane keeps a full
+    inversion batch (ecgpu_grid_oversubscribed: from 2^22 signatures per call on): at those sizes, ragged included, the signatures
+    must be byte-identical to the ones the throughput schedule (PUBLIC_SCALARS: table gathers, another kernel and grid) produces,
+    and the first and last few to the oracle's."""
+    import torch
+    import ecgpu
+    from oracle import synth
+    cv = ctx.curve(cn)
+    nb = cv.nb
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_d = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
+    d_k = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
+    d_z = torch.empty((n, nb), dtype=torch.uint8, device="cuda")
+    cv.synth_scalars_device(d_d, n, synth.SEED, 7)
+    cv.synth_scalars_device(d_k, n, synth.SEED, 7 + n)
+    cv.synth_scalars_device(d_z, n, synth.SEED, 7 + 2 * n)
+    outs = []
+    for fl in (ecgpu.SECRET_SCALARS, ecgpu.PUBLIC_SCALARS):
+        d_sig = torch.zeros((n, 2 * nb), dtype=torch.uint8, device="cuda")
+        d_rec = torch.zeros((n,), dtype=torch.uint8, device="cuda")
+        d_ok = torch.zeros((n,), dtype=torch.uint8, device="cuda")
+        cv.ecdsa_sign_device(d_d, d_k, d_z, d_sig, d_rec, d_ok, n, flags=fl | cv.default_ecdsa_flags())
+        ctx.synchronize()
+        outs.append((d_sig, d_rec, d_ok))
+    assert bool(outs[0][2].all())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    c = M.CURVES[cn]
+    sig = outs[0][0]
+    rec = outs[0][1]
+    for i in [0, 1, n // 2, n - 2, n - 1]:
+        d, k = (int.from_bytes(bytes(t[i].cpu().numpy()), "big") for t in (d_d, d_k))
+        want = M.ecdsa_sign_prehashed(c, d, k, bytes(d_z[i].cpu().numpy()), normalize_s=(cn == "k256"))
+        got = bytes(sig[i].cpu().numpy())
+        assert (int.from_bytes(got[:nb], "big"), int.from_bytes(got[nb:], "big"), int(rec[i])) == want, (cn, i)
+    ctx.set_stream(0)
+
+
 def test_bip340_schnorr_vectors_and_random(ctx, ref_vectors):
     """BIP340 sign vectors 0-3 and verify vectors 4-14 of k256/src/schnorr.rs, then random signatures made through the
     device (mul_by_generator) and systematic corruptions, all against the model."""
