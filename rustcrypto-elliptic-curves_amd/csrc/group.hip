@@ -238,8 +238,8 @@ static int gather_and_fold(ecgpu_group* g, int curve, uint8_t* out, int out_fmt)
   if (g->rccl_state == 1) {
     snprintf(g->gather_path, sizeof(g->gather_path), "rccl ncclAllGather, %d rank(s)", k);
     ncclResult_t r = g->rccl.GroupStart();
-    for (int i = 0; i < k && r == ncclSuccess; i++) {
-      GHIP(g, hipSetDevice(g->dev[i]));
+    for (int i = 0; i < k && r == ncclSuccess; i++) {                  // no early return in here: the group must be closed whatever happens
+      if (hipSetDevice(g->dev[i]) != hipSuccess) { r = ncclUnhandledCudaError; break; }
       r = g->rccl.AllGather(g->d_part[i], g->d_all[i], pt, ncclUint8, g->comms[i], g->ctx[i]->stream);
     }
     ncclResult_t r2 = g->rccl.GroupEnd();
