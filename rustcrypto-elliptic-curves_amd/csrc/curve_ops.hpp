@@ -285,7 +285,9 @@ struct CurveOps {
   // 3 .. 1024 terms per combination, throughput schedule (straus.hpp): groups of up to 16 terms share the doublings of one window
   // loop over per-term affine tables; a second small kernel adds the groups' partial sums and writes the outputs
   static int lincomb_straus(ecgpu_ctx* c, const u32* sc, const u32* pts, int pt_fmt, size_t terms, u32* out, int out_fmt, uint8_t* out_inf, size_t n) {
-    constexpr int WAVES = 4;
+    // waves per SIMD: secp256k1 runs 3 (168 VGPRs: 22 spilled instead of 119 at 4; -3 .. -5 % at 3 .. 64 terms), P-256 measures equal and
+    // P-384 was not timed at 3: both keep 4 (profiles/r04_ab_measurements.txt, set twelve)
+    constexpr int WAVES = C::ID == 0 ? 3 : 4;
     int g, gpc;
     straus::plan(n, terms, resident_lanes(c, WAVES), &g, &gpc);
     const size_t items = n * (size_t)gpc, upp = (size_t)(straus::SLOTS / g);

@@ -61,7 +61,7 @@ size_t CurveOps<CurveK256>::pass_units_points(const ecgpu_ctx* c, size_t terms, 
   if (flags & ECGPU_EXACT_REFERENCE) return resident_lanes(c, 4);                          // lincomb_ref_kernel: one unit per lane
   if (flags & ECGPU_SECRET_SCALARS) return ecgpuint_k256_ct_pass_units(c);
   if (terms == 2) return resident_lanes(c, 4) * 16;
-  if (terms > 2) return resident_lanes(c, 4);
+  if (terms > 2) return resident_lanes(c, 3);                                              // straus::lincomb_kernel<CurveK256, 3>
   return resident_lanes(c, c->opt[ECGPU_OPT_K256_WAVES] == 3 ? 3 : 4) * K256_FAST_BATCH;
 }
 // Pippenger MSM (msm.hpp, msm_kernels.hpp; instantiated in msm_k256.hip)
